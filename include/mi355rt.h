@@ -1,0 +1,251 @@
+/*
+ * mi355rt.h -- C ABI of the MI355X-native render loop.
+ *
+ * This is the drop-in boundary for ONE call of the reference:
+ *
+ *     let buffer = render_scene(&scene, &camera, &render_settings);      // src/main.rs:57
+ *     pub fn render_scene(scene: &Scene, camera: &Camera,
+ *                         render_settings: &RenderSettings) -> Vec<u32>  // src/renderer.rs:67
+ *
+ * The reference has no FFI of its own, so the entry points below are
+ * what a `#[repr(C)]` / `extern "C"` binding added at src/main.rs:57 would bind (the stub is in
+ * INTEGRATION.md).  Every struct is plain-old-data, little-endian f32/u32, no pointers inside
+ * arrays, and the caller owns every buffer it passes in.
+ *
+ * Conventions
+ *   - return value 0 = OK, negative = error; nothing aborts, nothing throws across the ABI;
+ *     mi355rt_last_error() returns a thread-local message for the last failure.
+ *   - output layout == render_scene's Vec<u32>: width*height, row-major, row 0 = top,
+ *     0x00RRGGBB (src/color.rs:87-93).
+ *   - matrices are column-major 4x4 as glam::Mat4 stores them (x_axis, y_axis, z_axis, w_axis).
+ *   - the top-level primitive array is walked in array order, exactly as
+ *     HittableList::hit walks `objects` (src/hittable.rs:45-58): order changes tie-breaks.
+ */
+#ifndef MI355RT_H
+#define MI355RT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355RT_ABI_VERSION 1u
+
+/* ---- error codes ------------------------------------------------------------------------- */
+#define MI355RT_OK               0
+#define MI355RT_ERR_INVALID     -1   /* malformed scene / settings / options                    */
+#define MI355RT_ERR_NO_DEVICE   -2   /* no usable HIP device (there is NO CPU fallback)          */
+#define MI355RT_ERR_HIP         -3   /* a HIP runtime call or a kernel failed                    */
+#define MI355RT_ERR_OOM         -4   /* host or device allocation failed                         */
+#define MI355RT_ERR_IO          -5   /* file could not be read / parsed (host-side loaders)      */
+#define MI355RT_ERR_UNSUPPORTED -6   /* feature flagged in the ABI but not built (e.g. skybox)   */
+
+/* ---- camera: src/camera.rs:4-11 (the fields of `Camera`, computed by Camera::new on the host) */
+typedef struct mi355rt_camera {
+    float position[3];
+    float forward[3];
+    float right[3];
+    float true_up[3];
+    float half_width;
+    float half_height;
+} mi355rt_camera;
+
+/* ---- render settings: src/tungsten/parser.rs:191-197 (`RenderSettings`) ---------------------- */
+typedef struct mi355rt_settings {
+    uint32_t width;
+    uint32_t height;
+    uint32_t samples_per_pixel;
+    uint32_t max_depth;
+} mi355rt_settings;
+
+/* ---- materials: the eight `impl Material` types (src/material.rs, src/tungsten/materials.rs) - */
+enum {
+    MI355RT_MAT_LAMBERT_SOLID   = 0, /* material.rs:47-71, AlbedoKind::Solid     albedo           */
+    MI355RT_MAT_LAMBERT_CHECKER = 1, /* material.rs:47-71, AlbedoKind::Checked   albedo=on, aux=off, p0=inv_scale */
+    MI355RT_MAT_METAL           = 2, /* material.rs:87-110                       albedo, p0=fuzz  */
+    MI355RT_MAT_DIELECTRIC      = 3, /* material.rs:122-162                      p0=refractive_index */
+    MI355RT_MAT_EMISSIVE        = 4, /* material.rs:169-192                      albedo=color     */
+    MI355RT_MAT_PLASTIC         = 5, /* tungsten/materials.rs:29-65              albedo, p0=ior   */
+    MI355RT_MAT_ROUGH_GGX       = 6, /* tungsten/materials.rs:306-377 (Ggx)      albedo, p0=roughness, eta, k */
+    MI355RT_MAT_ROUGH_BECKMANN  = 7, /* tungsten/materials.rs:306-377 (Beckmann) albedo, p0=roughness, eta, k */
+    MI355RT_MAT_NULL            = 8, /* material.rs:229-252 (never scatters, never emits)         */
+    MI355RT_MAT_KIND_COUNT      = 9
+};
+
+typedef struct mi355rt_material {      /* 64 bytes */
+    uint32_t kind;
+    float    albedo[3];
+    float    aux[3];
+    float    p0;
+    float    p1;
+    float    eta[3];                   /* MetalType::ior_k().0, tungsten/materials.rs:115-152      */
+    float    k[3];                     /* MetalType::ior_k().1                                     */
+    uint32_t _pad;
+} mi355rt_material;
+
+/* ---- top-level primitives: the five `impl Hittable` types ------------------------------------ */
+enum {
+    MI355RT_PRIM_SPHERE = 0, /* src/objects/sphere.rs:9-13   data: center[3], radius                */
+    MI355RT_PRIM_PLANE  = 1, /* src/objects/plane.rs:9-13    data: p1[3], normal[3] (unit)          */
+    MI355RT_PRIM_QUAD   = 2, /* src/tungsten/objects/quad.rs:10-21  data: base[3], edge0[3], edge1[3],
+                                normal[3], d, inv_edge0_len_sq, inv_edge1_len_sq                    */
+    MI355RT_PRIM_CUBE   = 3, /* src/objects/cube.rs:11-17    data: object_to_world[16], world_to_object[16] */
+    MI355RT_PRIM_MESH   = 4, /* src/mesh/mesh_object.rs:17-22 data: object_to_world[16], world_to_object[16];
+                                `mesh` indexes mi355rt_scene.meshes                                 */
+    MI355RT_PRIM_KIND_COUNT = 5
+};
+
+typedef struct mi355rt_primitive {     /* 144 bytes */
+    uint32_t kind;
+    uint32_t material;                 /* index into mi355rt_scene.materials                       */
+    uint32_t mesh;                     /* MI355RT_PRIM_MESH only                                   */
+    uint32_t _pad;
+    float    data[32];
+} mi355rt_primitive;
+
+/* ---- mesh payload: src/mesh/triangle.rs:5-11 and src/acceleration/bvh.rs:7-12 ----------------- */
+typedef struct mi355rt_triangle {      /* object space, 48 bytes; `material` lives on the primitive */
+    float v0[3];
+    float v1[3];
+    float v2[3];
+    float normal[3];                   /* Triangle::new, triangle.rs:14-25                          */
+} mi355rt_triangle;
+
+/* One BVHNode, flattened by any visitor.  Indices are relative to the owning mesh's
+ * first_node / first_index.  Inner node: index_count == 0, left/right = child node indices.
+ * Leaf: index_count > 0 and [first_index, first_index+index_count) is its `triangle_indices`
+ * list (values index the mesh's triangles).  Node 0 of a mesh is its root.                       */
+typedef struct mi355rt_bvh_node {      /* 40 bytes */
+    float    bmin[3];
+    float    bmax[3];
+    uint32_t left;
+    uint32_t right;
+    uint32_t first_index;
+    uint32_t index_count;
+} mi355rt_bvh_node;
+
+typedef struct mi355rt_mesh {
+    uint32_t first_triangle, triangle_count;   /* range in mi355rt_scene.triangles               */
+    uint32_t first_node, node_count;           /* range in mi355rt_scene.nodes                    */
+    uint32_t first_index, index_count;         /* range in mi355rt_scene.tri_indices              */
+    uint32_t max_depth;                        /* depth of the deepest node (root = 0); 0 = unknown */
+    uint32_t _pad;
+} mi355rt_mesh;
+
+/* ---- the scene: src/scene.rs:6-10 flattened --------------------------------------------------- */
+typedef struct mi355rt_scene {
+    const mi355rt_primitive* primitives;  uint32_t n_primitives;
+    const mi355rt_material*  materials;   uint32_t n_materials;
+    const mi355rt_mesh*      meshes;      uint32_t n_meshes;
+    const mi355rt_triangle*  triangles;   uint32_t n_triangles;
+    const mi355rt_bvh_node*  nodes;       uint32_t n_nodes;
+    const uint32_t*          tri_indices; uint32_t n_tri_indices;
+    float        miss_color[3];           /* Color::GRAY at HEAD, src/renderer.rs:61             */
+    uint32_t     sky_width, sky_height;   /* equirect HDR skybox, src/renderer.rs:40-54; 0 = none */
+    const float* sky_rgb;                 /* sky_width*sky_height*3; not built yet -> UNSUPPORTED */
+} mi355rt_scene;
+
+/* ---- options that have no counterpart in the reference ---------------------------------------- */
+enum {
+    MI355RT_RNG_CTR = 0, /* counter-based per-ray Philox4x32-10 keyed by (row y; x, sample, ray, block).
+                            GPU-native default; any tiling gives bit-identical images.           */
+    MI355RT_RNG_REF = 1  /* replay of the reference stream: StdRng::seed_from_u64(y) shared by a
+                            whole row (src/renderer.rs:91). One lane per row -- validation only.   */
+};
+
+typedef struct mi355rt_options {
+    uint32_t abi_version;     /* MI355RT_ABI_VERSION                                               */
+    uint32_t rng_mode;        /* MI355RT_RNG_*                                                     */
+    uint64_t seed;            /* 0 reproduces the reference: row key = y + seed                    */
+    /* Row selection. Rows are dealt in strips of `strip_rows` rows; this call renders the strips
+     * with (strip_index % n_parts) == part, restricted to [row_begin, row_end).  The output
+     * buffers then hold ONLY those rows, packed in ascending row order.
+     * {0, height, 1, 1, 0} renders the whole image.  row_end == 0 means `height`.               */
+    uint32_t row_begin, row_end;
+    uint32_t strip_rows, n_parts, part;
+    uint32_t _pad;
+    uint64_t workspace_bytes; /* cap for the per-sample radiance workspace in HBM; 0 = default     */
+} mi355rt_options;
+
+typedef struct mi355rt_stats {
+    double   render_kernel_ms;   /* sum over bands of the path-tracing kernel, HIP events          */
+    double   resolve_kernel_ms;  /* sum over bands of the ordered sum + gamma + pack kernel        */
+    double   total_ms;           /* first launch -> last kernel done (device timeline)             */
+    uint64_t samples;            /* camera paths started                                           */
+    uint64_t rays;               /* trace_ray invocations that intersected the scene               */
+    uint32_t rows_rendered;
+    uint32_t bands;
+    uint32_t grid_blocks, block_threads;
+    uint32_t kernel_vgprs, kernel_sgprs;   /* 0 if the runtime does not report them                */
+} mi355rt_stats;
+
+/* ---- one-shot call: host buffers in, host buffers out (what src/main.rs:57 would call) -------- */
+int mi355rt_render(const mi355rt_scene* scene, const mi355rt_camera* camera,
+                   const mi355rt_settings* settings, const mi355rt_options* options_or_null,
+                   uint32_t* out_packed_rgb,       /* rows_rendered*width, 0x00RRGGBB              */
+                   float*    out_linear_rgb_or_null,/* rows_rendered*width*3, pre-gamma mean       */
+                   mi355rt_stats* stats_or_null);
+
+/* ---- resident-scene API: upload once, render many times, device-side outputs ------------------ */
+typedef struct mi355rt_context mi355rt_context;
+
+int  mi355rt_context_create(int hip_device, mi355rt_context** out_ctx);
+void mi355rt_context_destroy(mi355rt_context* ctx);
+int  mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene,
+                               const mi355rt_camera* camera, const mi355rt_settings* settings);
+/* Number of rows the given options select (so callers can size their buffers).                  */
+int  mi355rt_rows_selected(const mi355rt_settings* settings, const mi355rt_options* options_or_null,
+                           uint32_t* out_rows);
+/* Enqueue a render on `hip_stream` (a hipStream_t, or NULL for the default stream).  Outputs are
+ * DEVICE pointers.  The call returns after the work is enqueued unless `stats_or_null` is given,
+ * in which case it synchronises the stream to read the timers.                                   */
+int  mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* options_or_null,
+                            void* d_out_packed_rgb, void* d_out_linear_rgb_or_null,
+                            void* hip_stream, mi355rt_stats* stats_or_null);
+
+const char* mi355rt_last_error(void);
+uint32_t    mi355rt_abi_version(void);
+
+/* =================================================================================================
+ * Host-side helpers (libmi355rt_host.so, pure CPU).  They stand in for the parts of the Rust host
+ * that cannot be built here: the producers of the arrays above.
+ * ================================================================================================= */
+
+/* BVHNode::new (src/acceleration/bvh.rs:15-76) over object-space triangles: median split on the
+ * largest-extent axis, leaf when <= 4 triangles or depth >= 25.  Ties in the centroid sort are kept
+ * in current slice order (the reference's sort_unstable_by tie order is unspecified).
+ * Two-call pattern: pass NULL arrays to get the counts.                                           */
+int mi355rt_bvh_build(const mi355rt_triangle* triangles, uint32_t n_triangles,
+                      mi355rt_bvh_node* out_nodes, uint32_t* inout_n_nodes,
+                      uint32_t* out_indices, uint32_t* inout_n_indices,
+                      uint32_t* out_max_depth);
+
+/* load_scene_from_json (src/tungsten/parser.rs:245-815) + Camera::new (src/camera.rs:14-31) +
+ * Mesh::from_obj / from_wo3 (src/mesh/mesh_object.rs:59-259).  Overrides replace the values parsed
+ * at parser.rs:260-285 (0 = keep the file's value).                                               */
+typedef struct mi355rt_loaded_scene mi355rt_loaded_scene;
+
+typedef struct mi355rt_load_overrides {
+    uint32_t width, height, samples_per_pixel, max_depth;
+    uint32_t skip_unknown_primitives;  /* 0 = hard error like serde (parser.rs:135-165), 1 = skip   */
+    uint32_t _pad;
+} mi355rt_load_overrides;
+
+int  mi355rt_scene_load_json(const char* json_path, const mi355rt_load_overrides* overrides_or_null,
+                             mi355rt_loaded_scene** out_scene);
+void mi355rt_scene_free(mi355rt_loaded_scene* s);
+const mi355rt_scene*    mi355rt_loaded_scene_get(const mi355rt_loaded_scene* s);
+const mi355rt_camera*   mi355rt_loaded_scene_camera(const mi355rt_loaded_scene* s);
+const mi355rt_settings* mi355rt_loaded_scene_settings(const mi355rt_loaded_scene* s);
+
+/* save_image's pixel conversion (src/renderer.rs:125-143) into an 8-bit RGB PNG.                  */
+int mi355rt_write_png(const char* path, const uint32_t* packed_rgb, uint32_t width, uint32_t height);
+
+const char* mi355rt_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355RT_H */
