@@ -1,0 +1,103 @@
+"""Build recipes for the native libraries (in-tree, gfx950 only).
+
+  libmi355rt.so       hipcc: HIP kernels + the device half of the C ABI (csrc/device)
+  libmi355rt_host.so  g++:   CPU-side producers -- scene loader, mesh readers, BVH build, PNG (csrc/host)
+  rt_render           g++:   CLI that stands in for the Rust `main` (csrc/tools)
+
+Outputs go to raytracer-rust_amd/_build/ (git-ignored, but they travel to the GPU box with gpurun).
+hipcc cross-compiles gfx950 without a GPU, so this also runs in the CPU-only container.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(HERE, "_build")
+CSRC = os.path.join(HERE, "csrc")
+
+DEVICE_SO = os.path.join(OUT, "libmi355rt.so")
+HOST_SO = os.path.join(OUT, "libmi355rt_host.so")
+CLI = os.path.join(OUT, "rt_render")
+
+# -ffp-contract=off: no FMA contraction -- the reference (rustc) never fuses a*b+c, and parity with the
+# CPU oracle is bit-level.  Correctly rounded f32 divide/sqrt are HIP's default; stated explicitly.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-command-line-argument"]
+CXX_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-pthread"]
+
+DEVICE_SRCS = [os.path.join(CSRC, "device", "rt_kernels.hip"), os.path.join(CSRC, "device", "rt_api.cpp")]
+DEVICE_DEPS = DEVICE_SRCS + [os.path.join(CSRC, "device", "rt_device.h"), os.path.join(ROOT, "include", "mi355rt.h")]
+
+
+def _host_srcs():
+    d = os.path.join(CSRC, "host")
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".cpp")) if os.path.isdir(d) else []
+
+
+def _host_deps():
+    d = os.path.join(CSRC, "host")
+    hs = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hpp", ".h"))) if os.path.isdir(d) else []
+    return _host_srcs() + hs + [os.path.join(ROOT, "include", "mi355rt.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def hipcc_path():
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found: the HIP path cannot be built (there is no CPU fallback)")
+    return p
+
+
+def build_device(force=False, extra_flags=(), verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    if force or _stale(DEVICE_SO, DEVICE_DEPS):
+        cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-o", DEVICE_SO, *DEVICE_SRCS]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return DEVICE_SO
+
+
+def build_host(force=False, verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    srcs = _host_srcs()
+    if not srcs:
+        raise RuntimeError("csrc/host has no sources")
+    if force or _stale(HOST_SO, _host_deps()):
+        cmd = ["g++", *CXX_FLAGS, "-shared", "-o", HOST_SO, *srcs, "-lz"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_SO
+
+
+def build_cli(force=False, verbose=False):
+    src = os.path.join(CSRC, "tools", "rt_render.cpp")
+    if not os.path.exists(src):
+        return None
+    build_device(force=False)
+    build_host(force=False)
+    if force or _stale(CLI, [src, DEVICE_SO, HOST_SO]):
+        cmd = ["g++", *CXX_FLAGS, "-o", CLI, src, "-L" + OUT, "-lmi355rt", "-lmi355rt_host",
+               "-Wl,-rpath,$ORIGIN", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CLI
+
+
+def build_all(force=False, verbose=False):
+    return build_device(force, verbose=verbose), build_host(force, verbose=verbose), build_cli(force, verbose=verbose)
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,381 @@
+// rt_api.cpp -- implementation of the device half of include/mi355rt.h (libmi355rt.so).
+//
+// Replaces `render_scene(&scene, &camera, &render_settings) -> Vec<u32>` (src/renderer.rs:67,
+// called from src/main.rs:57).  There is NO CPU fallback in this library: without a HIP device every
+// render entry point returns MI355RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/mi355rt.h"
+#include "rt_device.h"
+
+using namespace mi355rt;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                              \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? MI355RT_ERR_OOM : MI355RT_ERR_HIP, \
+         std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct RowSel { std::vector<uint32_t> rows; };
+
+int select_rows(const mi355rt_settings& st, const mi355rt_options* o, RowSel& sel) {
+    uint32_t rb = 0, re = st.height, strip = 1, parts = 1, part = 0;
+    if (o) {
+        if (o->abi_version != MI355RT_ABI_VERSION) return fail(MI355RT_ERR_INVALID, "options.abi_version mismatch");
+        rb = o->row_begin; re = o->row_end ? o->row_end : st.height;
+        strip = o->strip_rows ? o->strip_rows : 1; parts = o->n_parts ? o->n_parts : 1; part = o->part;
+        if (o->rng_mode != MI355RT_RNG_CTR && o->rng_mode != MI355RT_RNG_REF) return fail(MI355RT_ERR_INVALID, "options.rng_mode");
+    }
+    if (re > st.height || rb > re || part >= parts) return fail(MI355RT_ERR_INVALID, "row selection out of range");
+    sel.rows.clear();
+    for (uint32_t y = rb; y < re; ++y) if ((y / strip) % parts == part) sel.rows.push_back(y);
+    return MI355RT_OK;
+}
+
+int check_settings(const mi355rt_settings* st) {
+    if (!st) return fail(MI355RT_ERR_INVALID, "settings is null");
+    if (st->width == 0 || st->height == 0 || st->samples_per_pixel == 0) return fail(MI355RT_ERR_INVALID, "width/height/spp must be > 0");
+    if ((uint64_t)st->width * st->height >= (1ull << 31)) return fail(MI355RT_ERR_INVALID, "image too large");
+    if (st->width >= (1u << 24) || st->height >= (1u << 24)) return fail(MI355RT_ERR_INVALID, "width/height must be < 2^24 (x as f32 is exact, renderer.rs:96)");
+    if (st->samples_per_pixel >= (1u << 30)) return fail(MI355RT_ERR_INVALID, "samples_per_pixel too large");
+    return MI355RT_OK;
+}
+
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n && p) return MI355RT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (count == 0) count = 1;
+        HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+        return MI355RT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct mi355rt_context {
+    int device = 0;
+    int cu_count = 0;
+    int blocks_per_cu = 0, vgprs = 0, sgprs = 0;
+    bool have_scene = false;
+    mi355rt_settings settings{};
+    DevCamera cam{};
+    float miss[3] = {0.5f, 0.5f, 0.5f};
+    uint32_t n_prims = 0, n_mats = 0;
+    DevBuf<DevPrim> prims; DevBuf<DevMat> mats; DevBuf<DevNode> nodes; DevBuf<DevTri> tris;
+    DevBuf<uint32_t> rows; DevBuf<float> radiance; DevBuf<uint32_t> counters; DevBuf<unsigned long long> stats;
+    DevBuf<float> fold_stack;
+    std::vector<uint32_t> rows_host;     // source of the async row-table upload; must outlive the copy
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+// Re-lay one mesh's BVH (any node order, explicit child indices -- the shape of BVHNode, bvh.rs:7-12)
+// into the threaded pre-order form the kernel walks, and its triangles into leaf order.
+int flatten_mesh(const mi355rt_scene* sc, const mi355rt_mesh& m, std::vector<DevNode>& out_nodes, std::vector<DevTri>& out_tris,
+                 uint32_t& node_begin, uint32_t& node_end) {
+    if ((uint64_t)m.first_triangle + m.triangle_count > sc->n_triangles || m.triangle_count == 0) return fail(MI355RT_ERR_INVALID, "mesh triangle range");
+    if ((uint64_t)m.first_node + m.node_count > sc->n_nodes || m.node_count == 0) return fail(MI355RT_ERR_INVALID, "mesh node range (is the BVH missing? see mi355rt_bvh_build)");
+    if ((uint64_t)m.first_index + m.index_count > sc->n_tri_indices) return fail(MI355RT_ERR_INVALID, "mesh index range");
+    const mi355rt_bvh_node* nodes = sc->nodes + m.first_node;
+    const uint32_t* indices = sc->tri_indices + m.first_index;
+    const mi355rt_triangle* tris = sc->triangles + m.first_triangle;
+    node_begin = (uint32_t)out_nodes.size();
+    // iterative pre-order with an explicit stack of (node, fixup slot) -- input depth is not trusted
+    std::vector<uint32_t> stack;         // nodes still to visit (right children)
+    std::vector<std::pair<uint32_t, uint32_t>> open;   // (output index of inner node, remaining children)
+    uint32_t visited = 0;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        uint32_t ni = stack.back(); stack.pop_back();
+        if (ni >= m.node_count) return fail(MI355RT_ERR_INVALID, "BVH child index out of range");
+        if (++visited > m.node_count) return fail(MI355RT_ERR_INVALID, "BVH has a cycle or shared nodes");
+        const mi355rt_bvh_node& n = nodes[ni];
+        DevNode d;
+        std::memcpy(d.bmin, n.bmin, 12); std::memcpy(d.bmax, n.bmax, 12);
+        const uint32_t my = (uint32_t)out_nodes.size();
+        if (n.index_count > 0) {
+            if ((uint64_t)n.first_index + n.index_count > m.index_count) return fail(MI355RT_ERR_INVALID, "BVH leaf index range");
+            d.a = (uint32_t)out_tris.size(); d.b = n.index_count;
+            for (uint32_t k = 0; k < n.index_count; ++k) {
+                uint32_t id = indices[n.first_index + k];
+                if (id >= m.triangle_count) return fail(MI355RT_ERR_INVALID, "BVH leaf triangle id out of range");
+                const mi355rt_triangle& t = tris[id];
+                DevTri dt;
+                for (int c = 0; c < 3; ++c) { dt.v0[c] = t.v0[c]; dt.e1[c] = t.v1[c] - t.v0[c]; dt.e2[c] = t.v2[c] - t.v0[c]; dt.n[c] = t.normal[c]; }
+                out_tris.push_back(dt);
+            }
+            out_nodes.push_back(d);
+            // a finished leaf closes every inner node whose last child it was
+            while (!open.empty() && --open.back().second == 0) { out_nodes[open.back().first].a = (uint32_t)out_nodes.size(); open.pop_back(); }
+        } else {
+            d.a = 0; d.b = 0;
+            out_nodes.push_back(d);
+            open.emplace_back(my, 2u);
+            stack.push_back(n.right);     // visited after the whole left subtree
+            stack.push_back(n.left);
+        }
+    }
+    if (!open.empty()) return fail(MI355RT_ERR_INVALID, "BVH malformed");
+    node_end = (uint32_t)out_nodes.size();
+    return MI355RT_OK;
+}
+
+int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
+    if (!sc) return fail(MI355RT_ERR_INVALID, "scene is null");
+    if (sc->sky_rgb || sc->sky_width || sc->sky_height) return fail(MI355RT_ERR_UNSUPPORTED, "HDR skybox (renderer.rs:40-54) is not built yet");
+    if (sc->n_primitives && !sc->primitives) return fail(MI355RT_ERR_INVALID, "primitives is null");
+    if (sc->n_materials && !sc->materials) return fail(MI355RT_ERR_INVALID, "materials is null");
+    for (uint32_t i = 0; i < sc->n_materials; ++i)
+        if (sc->materials[i].kind >= MI355RT_MAT_KIND_COUNT) return fail(MI355RT_ERR_INVALID, "material kind");
+
+    std::vector<DevNode> nodes; std::vector<DevTri> tris;
+    std::vector<std::pair<uint32_t, uint32_t>> mesh_ranges(sc->n_meshes);
+    for (uint32_t m = 0; m < sc->n_meshes; ++m) {
+        int rc = flatten_mesh(sc, sc->meshes[m], nodes, tris, mesh_ranges[m].first, mesh_ranges[m].second);
+        if (rc) return rc;
+    }
+    std::vector<DevPrim> prims(sc->n_primitives);
+    for (uint32_t i = 0; i < sc->n_primitives; ++i) {
+        const mi355rt_primitive& p = sc->primitives[i];
+        DevPrim& d = prims[i];
+        std::memset(&d, 0, sizeof d);
+        if (p.kind >= MI355RT_PRIM_KIND_COUNT) return fail(MI355RT_ERR_INVALID, "primitive kind");
+        if (p.material >= sc->n_materials) return fail(MI355RT_ERR_INVALID, "primitive material index");
+        d.kind = p.kind; d.material = p.material;
+        if (p.kind == MI355RT_PRIM_CUBE || p.kind == MI355RT_PRIM_MESH) {
+            const float* o2w = p.data; const float* w2o = p.data + 16;
+            std::memcpy(d.d, w2o, 64);
+            for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) d.d[16 + 3 * c + r] = o2w[4 * c + r];
+            volatile float zero = 0.0f;                       // keep the IEEE product (sign of zero, NaN) exactly
+            for (int r = 0; r < 3; ++r) d.d[28 + r] = w2o[12 + r] * zero;
+            for (int r = 0; r < 3; ++r) d.d[31 + r] = w2o[4 * r + 3] * zero;
+            if (p.kind == MI355RT_PRIM_MESH) {
+                if (p.mesh >= sc->n_meshes) return fail(MI355RT_ERR_INVALID, "primitive mesh index");
+                d.node_begin = mesh_ranges[p.mesh].first; d.node_end = mesh_ranges[p.mesh].second;
+            }
+        } else {
+            std::memcpy(d.d, p.data, 32 * sizeof(float));
+        }
+    }
+    int rc;
+    if ((rc = ctx->prims.ensure(prims.size()))) return rc;
+    if ((rc = ctx->mats.ensure(sc->n_materials))) return rc;
+    if ((rc = ctx->nodes.ensure(nodes.size()))) return rc;
+    if ((rc = ctx->tris.ensure(tris.size()))) return rc;
+    static_assert(sizeof(DevMat) == sizeof(mi355rt_material), "material layout is shared with the ABI");
+    if (!prims.empty()) HIP_TRY(hipMemcpy(ctx->prims.p, prims.data(), prims.size() * sizeof(DevPrim), hipMemcpyHostToDevice));
+    if (sc->n_materials) HIP_TRY(hipMemcpy(ctx->mats.p, sc->materials, sc->n_materials * sizeof(DevMat), hipMemcpyHostToDevice));
+    if (!nodes.empty()) HIP_TRY(hipMemcpy(ctx->nodes.p, nodes.data(), nodes.size() * sizeof(DevNode), hipMemcpyHostToDevice));
+    if (!tris.empty()) HIP_TRY(hipMemcpy(ctx->tris.p, tris.data(), tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
+    ctx->n_prims = sc->n_primitives; ctx->n_mats = sc->n_materials;
+    std::memcpy(ctx->miss, sc->miss_color, 12);
+    return MI355RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mi355rt_last_error(void) { return g_err.c_str(); }
+uint32_t mi355rt_abi_version(void) { return MI355RT_ABI_VERSION; }
+
+int mi355rt_rows_selected(const mi355rt_settings* settings, const mi355rt_options* options, uint32_t* out_rows) {
+    int rc = check_settings(settings); if (rc) return rc;
+    if (!out_rows) return fail(MI355RT_ERR_INVALID, "out_rows is null");
+    RowSel sel; rc = select_rows(*settings, options, sel); if (rc) return rc;
+    *out_rows = (uint32_t)sel.rows.size();
+    return MI355RT_OK;
+}
+
+int mi355rt_context_create(int hip_device, mi355rt_context** out_ctx) {
+    if (!out_ctx) return fail(MI355RT_ERR_INVALID, "out_ctx is null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MI355RT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (hip_device < 0 || hip_device >= n) return fail(MI355RT_ERR_NO_DEVICE, "hip_device out of range");
+    HIP_TRY(hipSetDevice(hip_device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, hip_device));
+    mi355rt_context* ctx = new (std::nothrow) mi355rt_context();
+    if (!ctx) return fail(MI355RT_ERR_OOM, "host allocation failed");
+    ctx->device = hip_device;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (query_render_ctr_occupancy(&ctx->blocks_per_cu, &ctx->vgprs, &ctx->sgprs) != 0 || ctx->blocks_per_cu <= 0) {
+        delete ctx;
+        return fail(MI355RT_ERR_HIP, std::string("kernel image not usable on this device (") + prop.gcnArchName + "); built for gfx950");
+    }
+    for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return fail(MI355RT_ERR_HIP, "hipEventCreate"); }
+    *out_ctx = ctx;
+    return MI355RT_OK;
+}
+
+void mi355rt_context_destroy(mi355rt_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    ctx->prims.release(); ctx->mats.release(); ctx->nodes.release(); ctx->tris.release(); ctx->rows.release();
+    ctx->radiance.release(); ctx->counters.release(); ctx->stats.release(); ctx->fold_stack.release();
+    for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, const mi355rt_camera* camera,
+                              const mi355rt_settings* settings) {
+    if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
+    if (!camera) return fail(MI355RT_ERR_INVALID, "camera is null");
+    int rc = check_settings(settings); if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->have_scene = false;
+    rc = build_device_scene(ctx, scene); if (rc) return rc;
+    static_assert(sizeof(DevCamera) == sizeof(mi355rt_camera), "camera layout is shared with the ABI");
+    std::memcpy(&ctx->cam, camera, sizeof(DevCamera));
+    ctx->settings = *settings;
+    ctx->have_scene = true;
+    return MI355RT_OK;
+}
+
+int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, void* d_out_packed, void* d_out_linear,
+                           void* hip_stream, mi355rt_stats* stats) {
+    if (!ctx || !ctx->have_scene) return fail(MI355RT_ERR_INVALID, "context has no scene");
+    if (!d_out_packed) return fail(MI355RT_ERR_INVALID, "d_out_packed is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const mi355rt_settings& st = ctx->settings;
+    RowSel sel; int rc = select_rows(st, opt, sel); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));   // the previous call's row-table upload may still read rows_host
+    ctx->rows_host.swap(sel.rows);
+    const uint32_t rng_mode = opt ? opt->rng_mode : (uint32_t)MI355RT_RNG_CTR;
+    const uint64_t seed = opt ? opt->seed : 0;
+    const uint32_t n_rows = (uint32_t)ctx->rows_host.size();
+    if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
+    if (n_rows == 0) return MI355RT_OK;
+
+    if ((rc = ctx->rows.ensure(n_rows))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->rows.p, ctx->rows_host.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    if ((rc = ctx->stats.ensure(2))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, 2 * sizeof(unsigned long long), stream));
+
+    double render_ms = 0, resolve_ms = 0, total_ms = 0;
+    uint32_t n_bands = 0, grid_blocks = 0, block_threads = 0;
+
+    if (rng_mode == MI355RT_RNG_REF) {
+        if ((rc = ctx->fold_stack.ensure((size_t)n_rows * std::max(st.max_depth, 1u) * 3))) return rc;
+        RefParams rp{};
+        rp.prims = ctx->prims.p; rp.mats = ctx->mats.p; rp.nodes = ctx->nodes.p; rp.tris = ctx->tris.p; rp.rows = ctx->rows.p;
+        rp.out_packed = (uint32_t*)d_out_packed; rp.out_linear = (float*)d_out_linear; rp.fold_stack = ctx->fold_stack.p; rp.stats = ctx->stats.p;
+        rp.n_prims = ctx->n_prims; rp.n_mats = ctx->n_mats; rp.n_rows = n_rows;
+        std::memcpy(rp.miss, ctx->miss, 12); rp.cam = ctx->cam;
+        rp.width = st.width; rp.height = st.height; rp.spp = st.samples_per_pixel; rp.max_depth = st.max_depth;
+        rp.seed_lo = (uint32_t)seed; rp.seed_hi = (uint32_t)(seed >> 32);
+        if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], stream));
+        if (launch_render_ref(rp, stream) != 0) return fail(MI355RT_ERR_HIP, "k_render_ref launch failed");
+        if (stats) {
+            HIP_TRY(hipEventRecord(ctx->ev[1], stream));
+            HIP_TRY(hipEventSynchronize(ctx->ev[1]));
+            float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            render_ms = total_ms = ms;
+        }
+        n_bands = 1; grid_blocks = (n_rows + 63) / 64; block_threads = 64;
+    } else {
+        // ---- band plan: the radiance workspace holds band_pixels * spp float4 ----
+        const uint64_t spp = st.samples_per_pixel;
+        const uint64_t total_pixels = (uint64_t)n_rows * st.width;
+        uint64_t ws_cap = (opt && opt->workspace_bytes) ? opt->workspace_bytes : (4ull << 30);
+        uint64_t max_samples = std::min<uint64_t>(ws_cap / 16, (1ull << 31) - BATCH_SAMPLES);
+        if (max_samples < spp) return fail(MI355RT_ERR_INVALID, "workspace_bytes too small for one pixel (needs spp * 16 bytes)");
+        const uint64_t band_pixels_max = std::min<uint64_t>(max_samples / spp, total_pixels);
+        n_bands = (uint32_t)((total_pixels + band_pixels_max - 1) / band_pixels_max);
+        if ((rc = ctx->radiance.ensure((size_t)(band_pixels_max * spp * 4)))) return rc;
+        if ((rc = ctx->counters.ensure(n_bands))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, (size_t)n_bands * sizeof(uint32_t), stream));
+
+        RenderParams p{};
+        p.prims = ctx->prims.p; p.mats = ctx->mats.p; p.nodes = ctx->nodes.p; p.tris = ctx->tris.p; p.rows = ctx->rows.p;
+        p.radiance = ctx->radiance.p; p.stats = ctx->stats.p;
+        p.n_prims = ctx->n_prims; p.n_mats = ctx->n_mats;
+        std::memcpy(p.miss, ctx->miss, 12); p.cam = ctx->cam;
+        p.width = st.width; p.height = st.height; p.spp = st.samples_per_pixel; p.max_depth = st.max_depth;
+        p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+        ResolveParams r{};
+        r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
+        r.spp = st.samples_per_pixel; r.inv_spp = 1.0f / (float)st.samples_per_pixel;     // renderer.rs:85
+        const uint32_t resident = (uint32_t)(ctx->cu_count * ctx->blocks_per_cu);
+        block_threads = BLOCK_THREADS;
+        std::vector<float> band_ms;
+        for (uint32_t b = 0; b < n_bands; ++b) {
+            const uint64_t p0 = (uint64_t)b * band_pixels_max;
+            const uint64_t np = std::min<uint64_t>(band_pixels_max, total_pixels - p0);
+            p.band_pixel0 = (uint32_t)p0; p.band_samples = (uint32_t)(np * spp);
+            p.n_batches = (p.band_samples + BATCH_SAMPLES - 1) / BATCH_SAMPLES;
+            p.batch_counter = ctx->counters.p + b;
+            const uint32_t waves_per_block = BLOCK_THREADS / 64;
+            const uint32_t grid = std::max(1u, std::min(resident, (p.n_batches + waves_per_block - 1) / waves_per_block));
+            grid_blocks = std::max(grid_blocks, grid);
+            r.band_pixel0 = (uint32_t)p0; r.band_pixels = (uint32_t)np;
+            if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], stream));
+            if (launch_render_ctr(p, grid, stream) != 0) return fail(MI355RT_ERR_HIP, "k_render_ctr launch failed");
+            if (stats) HIP_TRY(hipEventRecord(ctx->ev[1], stream));
+            if (launch_resolve(r, stream) != 0) return fail(MI355RT_ERR_HIP, "k_resolve launch failed");
+            if (stats) {
+                HIP_TRY(hipEventRecord(ctx->ev[2], stream));
+                HIP_TRY(hipEventSynchronize(ctx->ev[2]));
+                float a = 0, c = 0;
+                HIP_TRY(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+                HIP_TRY(hipEventElapsedTime(&c, ctx->ev[1], ctx->ev[2]));
+                render_ms += a; resolve_ms += c; total_ms += a + c;
+            }
+        }
+    }
+    if (stats) {
+        unsigned long long h[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(h, ctx->stats.p, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        stats->render_kernel_ms = render_ms; stats->resolve_kernel_ms = resolve_ms; stats->total_ms = total_ms;
+        stats->samples = h[0]; stats->rays = h[1];
+        stats->bands = n_bands; stats->grid_blocks = grid_blocks; stats->block_threads = block_threads;
+    }
+    return MI355RT_OK;
+}
+
+int mi355rt_render(const mi355rt_scene* scene, const mi355rt_camera* camera, const mi355rt_settings* settings,
+                   const mi355rt_options* opt, uint32_t* out_packed, float* out_linear, mi355rt_stats* stats) {
+    if (!out_packed) return fail(MI355RT_ERR_INVALID, "out_packed_rgb is null");
+    int rc = check_settings(settings); if (rc) return rc;
+    uint32_t n_rows = 0;
+    rc = mi355rt_rows_selected(settings, opt, &n_rows); if (rc) return rc;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(MI355RT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    mi355rt_context* ctx = nullptr;
+    rc = mi355rt_context_create(dev, &ctx); if (rc) return rc;
+    rc = mi355rt_context_set_scene(ctx, scene, camera, settings);
+    uint32_t* d_packed = nullptr; float* d_linear = nullptr;
+    const size_t npix = (size_t)n_rows * settings->width;
+    if (!rc && npix) {
+        if (hipMalloc((void**)&d_packed, npix * 4) != hipSuccess) rc = fail(MI355RT_ERR_OOM, "hipMalloc(out_packed)");
+        if (!rc && out_linear && hipMalloc((void**)&d_linear, npix * 12) != hipSuccess) rc = fail(MI355RT_ERR_OOM, "hipMalloc(out_linear)");
+        mi355rt_stats local{};
+        if (!rc) rc = mi355rt_context_render(ctx, opt, d_packed, d_linear, nullptr, stats ? stats : &local);
+        if (!rc && hipMemcpy(out_packed, d_packed, npix * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI355RT_ERR_HIP, "copy back packed");
+        if (!rc && out_linear && hipMemcpy(out_linear, d_linear, npix * 12, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI355RT_ERR_HIP, "copy back linear");
+    }
+    if (d_packed) (void)hipFree(d_packed);
+    if (d_linear) (void)hipFree(d_linear);
+    std::string keep = g_err;
+    mi355rt_context_destroy(ctx);
+    g_err = keep;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// rt_device.h -- device-resident scene layout and kernel launch interface (internal to libmi355rt.so).
+//
+// HBM layout (all arrays 16-byte aligned, record sizes multiples of 16 bytes so that the
+// wave-uniform top-level walk lowers to s_load_dwordx4/x8/x16 and the per-lane BVH walk to
+// global_load_dwordx4):
+//   DevPrim[n_prims]   176 B  top-level list in caller order (hittable.rs:45-58), read through the
+//                             constant address space with a wave-uniform index -> SGPRs
+//   DevMat[n_mats]      64 B  per-lane gather by material index (4 x dwordx4)
+//   DevNode[n_nodes]    32 B  per-mesh BVH in DFS pre-order ("threaded"): the left child of node i
+//                             is i+1; `a` is the escape index for inner nodes / first triangle for
+//                             leaves, `b` is 0 for inner nodes / triangle count for leaves
+//   DevTri[n_tris]      48 B  triangles re-ordered into leaf order, stored as v0, e1=v1-v0, e2=v2-v0,
+//                             normal (the same f32 subtractions bvh.rs:95-96 performs per test)
+//   rows[n_rows]         4 B  local output row -> absolute image row y (the RNG key)
+//   radiance[band]      16 B  one float4 per path (sample-major inside a pixel), written once by
+//                             the path tracer and read once by the resolve kernel
+#pragma once
+#include <stdint.h>
+
+namespace mi355rt {
+
+struct DevPrim {                 // 44 words = 176 B
+    uint32_t kind, material, node_begin, node_end;   // node range for MI355RT_PRIM_MESH
+    // sphere: c[3], r | plane: p1[3], n[3] | quad: base, e0, e1, n, d, inv0, inv1 (15)
+    // cube / mesh: w2o[16] (column-major), o2w rows 0..2 of its 4 columns as o2w[12] = {c0.xyz, c1.xyz, c2.xyz, c3.xyz},
+    //              zd[3] = w2o.w_axis.xyz * 0.0f, zn[3] = {w2o[3], w2o[7], w2o[11]} * 0.0f
+    float d[40];
+};
+static_assert(sizeof(DevPrim) == 176, "DevPrim must stay 16-byte granular");
+
+struct DevMat {                  // 64 B, same field order as mi355rt_material
+    uint32_t kind; float albedo[3];
+    float aux[3];  float p0;
+    float p1;      float eta[3];
+    float k[3];    uint32_t pad;
+};
+static_assert(sizeof(DevMat) == 64, "DevMat");
+
+struct DevNode { float bmin[3]; uint32_t a; float bmax[3]; uint32_t b; };
+static_assert(sizeof(DevNode) == 32, "DevNode");
+
+struct DevTri { float v0[3], e1[3], e2[3], n[3]; };
+static_assert(sizeof(DevTri) == 48, "DevTri");
+
+struct DevCamera { float position[3], forward[3], right[3], true_up[3], half_width, half_height; };
+
+constexpr uint32_t BATCH_SAMPLES = 1024;   // paths a wave claims per global atomic
+constexpr uint32_t BLOCK_THREADS = 256;
+
+struct RenderParams {
+    const DevPrim* prims; const DevMat* mats; const DevNode* nodes; const DevTri* tris;
+    const uint32_t* rows;        // local row -> absolute y
+    float* radiance;             // float4 per band sample
+    uint32_t* batch_counter;     // zeroed before each band
+    unsigned long long* stats;   // [0] = paths started, [1] = rays traced
+    uint32_t n_prims, n_mats;
+    float miss[3];
+    DevCamera cam;
+    uint32_t width, height, spp, max_depth;
+    uint32_t band_pixel0;        // first local pixel (row-major over the selected rows) of this band
+    uint32_t band_samples;       // band pixels * spp  (< 2^31)
+    uint32_t n_batches;
+    uint32_t seed_lo, seed_hi;
+};
+
+struct ResolveParams {
+    const float* radiance;       // float4 per band sample
+    uint32_t* out_packed;        // local pixels, 0x00RRGGBB
+    float* out_linear;           // local pixels * 3, may be null
+    uint32_t band_pixel0, band_pixels, spp;
+    float inv_spp;
+};
+
+struct RefParams {               // MI355RT_RNG_REF: one lane per selected row
+    const DevPrim* prims; const DevMat* mats; const DevNode* nodes; const DevTri* tris;
+    const uint32_t* rows;
+    uint32_t* out_packed; float* out_linear;
+    float* fold_stack;           // n_rows * max_depth * 3 floats (attenuation stack for tail-first folding)
+    unsigned long long* stats;
+    uint32_t n_prims, n_mats, n_rows;
+    float miss[3];
+    DevCamera cam;
+    uint32_t width, height, spp, max_depth;
+    uint32_t seed_lo, seed_hi;
+};
+
+// launchers (rt_kernels.hip); `stream` is a hipStream_t
+int launch_render_ctr(const RenderParams& p, uint32_t grid_blocks, void* stream);
+int launch_resolve(const ResolveParams& p, void* stream);
+int launch_render_ref(const RefParams& p, void* stream);
+int query_render_ctr_occupancy(int* blocks_per_cu, int* vgprs, int* sgprs);
+
+}  // namespace mi355rt

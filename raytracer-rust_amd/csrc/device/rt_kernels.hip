@@ -1,0 +1,729 @@
+// rt_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X) replacing the rayon per-pixel loop of
+// jackra1n/raytracer-rust (render_scene -> trace_ray, src/renderer.rs:19-123).
+//
+// Kernels
+//   k_render_ctr   persistent wave64 path tracer.  One lane = one path (one sample of one pixel).  A wave
+//                  claims BATCH_SAMPLES consecutive sample indices with ONE global atomic and deals them
+//                  to its lanes with ballot/mbcnt whenever lanes run dry (path regeneration), so lanes
+//                  whose paths end early (miss, emitter, absorption) are refilled on the next iteration
+//                  instead of idling until the longest path of the wave finishes.
+//                  The top-level primitive list is walked with a wave-uniform index through the constant
+//                  address space (scalar loads, records live in SGPRs); the per-mesh BVH is a threaded
+//                  pre-order array walked per lane with dwordx4 loads -- the reference always descends
+//                  left-then-right (bvh.rs:142-156), so escape links reproduce its visit order and its
+//                  shrinking t_max exactly and no traversal stack is needed.
+//                  Randomness: counter-based Philox4x32-10 keyed by the image row, counters
+//                  (x, sample, ray index, block): every draw is a pure function of the path, so any
+//                  schedule / tiling / GPU count produces bit-identical radiance.
+//                  Output: one float4 radiance per path into the HBM workspace.
+//   k_resolve      per pixel, sums its spp radiance values IN SAMPLE ORDER (renderer.rs:100), scales by
+//                  1/spp (:103), sqrt-gamma, clamp, pack 0x00RRGGBB (:112-120, color.rs:87-93).
+//   k_render_ref   validation mode: one lane per image row replays the reference's sequential
+//                  StdRng::seed_from_u64(y) stream (renderer.rs:91) and folds radiance tail-first.
+//
+// Numerics: compiled with -ffp-contract=off and correctly rounded f32 divide/sqrt; every expression
+// keeps the reference's operation order (file:line cited per function), so results agree with the
+// CPU oracle bit-for-bit wherever only + - * / sqrt are involved.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rt_device.h"
+#include "../../../include/mi355rt.h"
+
+namespace mi355rt {
+
+#define DI __device__ __forceinline__
+
+constexpr float EPS = 1e-4f;                      // renderer.rs:17
+constexpr float PI_F = 3.14159265358979323846f;   // std::f32::consts::PI
+
+typedef const __attribute__((address_space(4))) DevPrim* cprim_t;   // wave-uniform reads -> s_load
+
+// ---------------------------------------------------------------------------------------------------
+// vec3.rs
+// ---------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+DI f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+DI f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DI f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DI f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+DI f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }     // Color * Color
+DI f3 operator/(f3 a, f3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }     // Color / Color
+DI f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+DI f3 divf(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+DI float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }            // vec3.rs:17-19
+DI f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }  // :21-27
+DI float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }                 // :29-31
+DI float len(f3 a) { return sqrtf(len2(a)); }                                     // :33-35
+DI f3 normalized(f3 a) { float l = len(a); if (l < EPS) return a; return a * (1.0f / l); }   // :37-44
+DI bool near_zero(f3 a) { const float S = 1e-8f; return fabsf(a.x) < S && fabsf(a.y) < S && fabsf(a.z) < S; }  // :63-66
+DI bool has_nan(f3 a) { return (a.x != a.x) || (a.y != a.y) || (a.z != a.z); }
+DI bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+DI f3 nan3() { float n = __builtin_nanf(""); return mk(n, n, n); }
+DI f3 splat(float v) { return mk(v, v, v); }
+DI f3 sqrt3(f3 a) { return mk(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)); }
+DI f3 to_world(f3 local, f3 normal) {                                             // vec3.rs:72-81
+    f3 up = (fabsf(normal.z) < 0.999f) ? mk(0.f, 0.f, 1.f) : mk(0.f, 1.f, 0.f);
+    f3 tangent = normalized(cross(normal, up));
+    f3 bitangent = cross(normal, tangent);
+    return (tangent * local.x + bitangent * local.y) + normal * local.z;
+}
+DI float clamp01(float v) { if (v < 0.0f) return 0.0f; if (v > 1.0f) return 1.0f; return v; }   // f32::clamp, NaN stays
+DI uint32_t as_u32_sat(float v) {                                                 // Rust `as u32`
+    if (!(v == v) || v <= 0.0f) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+DI int32_t as_i32_sat(float v) {                                                  // Rust `as i32`
+    if (!(v == v)) return 0;
+    if (v <= -2147483648.0f) return (int32_t)0x80000000;
+    if (v >= 2147483648.0f) return 0x7FFFFFFF;
+    return (int32_t)v;
+}
+DI uint32_t color_to_u32(f3 c) {                                                  // color.rs:87-93
+    c.x = clamp01(c.x); c.y = clamp01(c.y); c.z = clamp01(c.z);
+    return (as_u32_sat(c.x * 255.0f) << 16) | (as_u32_sat(c.y * 255.0f) << 8) | as_u32_sat(c.z * 255.0f);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RNG: float conversions of rand 0.9.1 (StandardUniform<f32>, UniformFloat::sample_single(-1..1))
+// ---------------------------------------------------------------------------------------------------
+DI float u32_to_f01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+DI float u32_to_range11(uint32_t w) { float v12 = __uint_as_float((w >> 9) | 0x3F800000u); float v01 = v12 - 1.0f; return v01 * 2.0f + -1.0f; }
+
+// Philox4x32-10: counter-based, no state.  10 x (2 x 32x32->64 multiplies + 4 xor + 2 add).
+DI void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Counter mode sampler: draws are addressed, not consumed (slots documented in oracle/rt_oracle.cpp
+// and DESIGN.md): jitter = (ray 0, block 0, words 0/1); scatter event after ray r uses ray r+1:
+// random::<f32>() number k -> block 0 word k; rejection try j -> block j words 1..3.
+struct RngCtr {
+    uint32_t k0, k1, x, s, ray;
+    uint32_t b0[4];
+    DI void start(uint32_t k0_, uint32_t k1_, uint32_t x_, uint32_t s_) { k0 = k0_; k1 = k1_; x = x_; s = s_; ray = 0; philox4x32_10(k0, k1, x, s, 0u, 0u, b0); }
+    DI float jitter_u() { return u32_to_f01(b0[0]); }
+    DI float jitter_v() { return u32_to_f01(b0[1]); }
+    DI void begin_scatter() { ++ray; philox4x32_10(k0, k1, x, s, ray, 0u, b0); }
+    DI float uniform01_0() { return u32_to_f01(b0[0]); }
+    DI float uniform01_1() { return u32_to_f01(b0[1]); }
+    DI f3 cube_point(uint32_t j) {
+        if (j == 0) return mk(u32_to_range11(b0[1]), u32_to_range11(b0[2]), u32_to_range11(b0[3]));
+        uint32_t b[4]; philox4x32_10(k0, k1, x, s, ray, j, b);
+        return mk(u32_to_range11(b[1]), u32_to_range11(b[2]), u32_to_range11(b[3]));
+    }
+};
+
+// Reference mode sampler: rand_chacha ChaCha12 with the BlockRng 64-word buffer, seeded by
+// rand_core's seed_from_u64 (PCG32 expansion).  SURVEY.md Appendix A.
+DI uint32_t rotl(uint32_t v, int n) { return __builtin_rotateleft32(v, n); }
+struct RngRef {
+    uint32_t key[8]; uint32_t ctr_lo, ctr_hi; uint32_t idx; uint32_t buf[64];
+    DI void seed_from_u64(uint64_t state) {
+        for (int i = 0; i < 8; ++i) {
+            state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+            uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27);
+            uint32_t rot = (uint32_t)(state >> 59);
+            key[i] = __builtin_rotateright32(xs, rot);
+        }
+        ctr_lo = 0; ctr_hi = 0; idx = 64;
+    }
+    DI void block(uint32_t* out) {
+        uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                           key[4], key[5], key[6], key[7], ctr_lo, ctr_hi, 0u, 0u};
+        uint32_t x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = in[i];
+#define MI_QR(a, b, c, d) \
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 16); x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 12); \
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 8);  x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 7);
+        for (int r = 0; r < 6; ++r) {
+            MI_QR(0, 4, 8, 12) MI_QR(1, 5, 9, 13) MI_QR(2, 6, 10, 14) MI_QR(3, 7, 11, 15)
+            MI_QR(0, 5, 10, 15) MI_QR(1, 6, 11, 12) MI_QR(2, 7, 8, 13) MI_QR(3, 4, 9, 14)
+        }
+#undef MI_QR
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[i] = x[i] + in[i];
+        if (++ctr_lo == 0) ++ctr_hi;
+    }
+    DI uint32_t next_u32() {
+        if (idx >= 64) { for (int b = 0; b < 4; ++b) block(buf + 16 * b); idx = 0; }
+        return buf[idx++];
+    }
+    DI float jitter_u() { return u32_to_f01(next_u32()); }
+    DI float jitter_v() { return u32_to_f01(next_u32()); }
+    DI void begin_scatter() {}
+    DI float uniform01_0() { return u32_to_f01(next_u32()); }
+    DI float uniform01_1() { return u32_to_f01(next_u32()); }
+    DI f3 cube_point(uint32_t) { float x = u32_to_range11(next_u32()); float y = u32_to_range11(next_u32()); float z = u32_to_range11(next_u32()); return mk(x, y, z); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Intersection.  Hit record (hittable.rs:10-27) kept in registers; `mat_ff` = material | front_face<<31.
+// ---------------------------------------------------------------------------------------------------
+struct Hit { float t; f3 p; f3 n; uint32_t mat_ff; };
+
+DI void set_face(Hit& h, f3 rd, f3 outward, uint32_t material) {                 // hittable.rs:19-26
+    bool front = dot(rd, outward) < 0.0f;
+    h.n = front ? outward : -outward;
+    h.mat_ff = material | (front ? 0x80000000u : 0u);
+}
+
+// objects/sphere.rs:15-53
+DI bool hit_sphere(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
+    f3 center = mk(pr->d[0], pr->d[1], pr->d[2]); float radius = pr->d[3];
+    f3 oc = ro - center;
+    float a = dot(rd, rd);
+    float half_b = dot(oc, rd);
+    float c = dot(oc, oc) - radius * radius;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return false;
+    float sqrtd = sqrtf(disc);
+    float root = (-half_b - sqrtd) / a;
+    if (root <= t_min || root >= t_max) {
+        root = (-half_b + sqrtd) / a;
+        if (root <= t_min || root >= t_max) return false;
+    }
+    h.t = root;
+    h.p = ro + rd * root;
+    set_face(h, rd, divf(h.p - center, radius), pr->material);
+    return true;
+}
+
+// objects/plane.rs:26-56
+DI bool hit_plane(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
+    f3 p1 = mk(pr->d[0], pr->d[1], pr->d[2]), n = mk(pr->d[3], pr->d[4], pr->d[5]);
+    float denom = dot(n, rd);
+    if (fabsf(denom) < EPS) return false;
+    float t = dot(n, p1 - ro) / denom;
+    if (t <= t_min || t >= t_max) return false;
+    h.t = t; h.p = ro + rd * t;
+    set_face(h, rd, n, pr->material);
+    return true;
+}
+
+// tungsten/objects/quad.rs:83-132
+DI bool hit_quad(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
+    f3 n = mk(pr->d[9], pr->d[10], pr->d[11]);
+    float denom = dot(n, rd);
+    if (fabsf(denom) < EPS) return false;
+    float t = (pr->d[12] - dot(n, ro)) / denom;
+    if (t <= t_min || t >= t_max) return false;
+    f3 hit_pos = ro + rd * t;
+    f3 v = hit_pos - mk(pr->d[0], pr->d[1], pr->d[2]);
+    float l0 = dot(v, mk(pr->d[3], pr->d[4], pr->d[5])) * pr->d[13];
+    float l1 = dot(v, mk(pr->d[6], pr->d[7], pr->d[8])) * pr->d[14];
+    const float lo = -EPS, hi = 1.0f + EPS;
+    if (!((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi))) return false;
+    h.t = t; h.p = hit_pos;
+    set_face(h, rd, n, pr->material);
+    return true;
+}
+
+// glam Mat4 * Vec4 pieces on the DevPrim cube/mesh record (see rt_device.h for the layout)
+DI f3 xform_w2o_point(cprim_t pr, f3 p) {            // (w2o * (p, 1)).xyz
+    const auto* m = pr->d;
+    return mk(((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12], ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13],
+              ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14]);
+}
+DI f3 xform_w2o_dir(cprim_t pr, f3 v) {              // (w2o * (v, 0)).xyz ; zd = w_axis * 0.0f keeps -0.0 behaviour
+    const auto* m = pr->d;
+    return mk(((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[28], ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[29],
+              ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[30]);
+}
+DI f3 xform_o2w_point(cprim_t pr, f3 p) {            // (o2w * (p, 1)).xyz
+    const auto* m = pr->d + 16;
+    return mk(((m[0] * p.x + m[3] * p.y) + m[6] * p.z) + m[9], ((m[1] * p.x + m[4] * p.y) + m[7] * p.z) + m[10],
+              ((m[2] * p.x + m[5] * p.y) + m[8] * p.z) + m[11]);
+}
+DI f3 xform_normal(cprim_t pr, f3 n) {               // (w2o.transpose() * (n, 0)).xyz
+    const auto* m = pr->d;
+    return mk(((m[0] * n.x + m[1] * n.y) + m[2] * n.z) + m[31], ((m[4] * n.x + m[5] * n.y) + m[6] * n.z) + m[32],
+              ((m[8] * n.x + m[9] * n.y) + m[10] * n.z) + m[33]);
+}
+DI float glam_signum(float v) { if (v != v) return v; return copysignf(1.0f, v); }
+
+// objects/cube.rs:59-158
+DI bool hit_cube(cprim_t pr, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h) {
+    f3 ro = xform_w2o_point(pr, ro_w);
+    f3 rd = xform_w2o_dir(pr, rd_w);
+    float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
+    float t1x = (-0.5f - ro.x) * ix, t2x = (0.5f - ro.x) * ix;
+    float t1y = (-0.5f - ro.y) * iy, t2y = (0.5f - ro.y) * iy;
+    float t1z = (-0.5f - ro.z) * iz, t2z = (0.5f - ro.z) * iz;
+    float t_enter = fmaxf(fminf(t1x, t2x), fmaxf(fminf(t1y, t2y), fminf(t1z, t2z)));
+    float t_exit = fminf(fmaxf(t1x, t2x), fminf(fmaxf(t1y, t2y), fmaxf(t1z, t2z)));
+    if (t_exit < t_enter || t_exit <= 0.0f) return false;
+    float t_hit = (t_enter > 0.0f) ? t_enter : t_exit;
+    if (t_hit >= t_max || t_hit <= t_min || t_hit < EPS) return false;
+    f3 po = ro + rd * t_hit;
+    f3 n = mk(0.f, 0.f, 0.f);
+    float ax = fabsf(po.x), ay = fabsf(po.y), az = fabsf(po.z);
+    const float tol = 1e-4f;
+    if (fabsf(ax - 0.5f) < tol) n.x = glam_signum(po.x);
+    else if (fabsf(ay - 0.5f) < tol) n.y = glam_signum(po.y);
+    else if (fabsf(az - 0.5f) < tol) n.z = glam_signum(po.z);
+    else if (ax > ay && ax > az) n.x = glam_signum(po.x);
+    else if (ay > az) n.y = glam_signum(po.y);
+    else n.z = glam_signum(po.z);
+    {   // Vec3::normalize_or_zero
+        float rcp = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+        if (isfinite(rcp) && rcp > 0.0f) n = n * rcp; else n = mk(0.f, 0.f, 0.f);
+    }
+    f3 pw = xform_o2w_point(pr, po);
+    f3 nw = normalized(xform_normal(pr, n));
+    if (dot(pw - ro_w, rd_w) < 0.0f) return false;
+    float t_world = dot(pw - ro_w, rd_w);
+    if (t_world < t_min || t_world > t_max) return false;
+    h.t = t_world; h.p = pw;
+    set_face(h, rd_w, nw, pr->material);
+    return true;
+}
+
+// mesh/mesh_object.rs:263-329 + acceleration/bvh.rs:78-170 + acceleration/aabb.rs:27-45.
+// Threaded pre-order walk; `best_t` plays the role of the recursion's shrinking t_max.
+DI bool hit_mesh(cprim_t pr, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro_w, f3 rd_w,
+                 float t_min, float t_max, Hit& h) {
+    f3 ro = xform_w2o_point(pr, ro_w);
+    f3 rd_raw = xform_w2o_dir(pr, rd_w);
+    f3 rd = normalized(normalized(rd_raw));              // Ray::new(o, d.normalized()), mesh_object.rs:289
+    const float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;   // aabb.rs:29 (same value at every node)
+    uint32_t node = pr->node_begin;
+    const uint32_t end = pr->node_end;
+    float best_t = t_max; uint32_t best_tri = 0xFFFFFFFFu;
+    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(nodes);
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(tris);
+    while (node < end) {
+        const float4 q0 = n4[2 * (size_t)node], q1 = n4[2 * (size_t)node + 1];
+        const uint32_t a = __float_as_uint(q0.w), b = __float_as_uint(q1.w);
+        float tmin = t_min, tmax = best_t;
+        bool ok = true;
+        {   float t0 = (q0.x - ro.x) * ix, t1 = (q1.x - ro.x) * ix; if (ix < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+            tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
+        {   float t0 = (q0.y - ro.y) * iy, t1 = (q1.y - ro.y) * iy; if (iy < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+            tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
+        {   float t0 = (q0.z - ro.z) * iz, t1 = (q1.z - ro.z) * iz; if (iz < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+            tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
+        if (!ok) { node = b ? node + 1 : a; continue; }   // skip subtree (a leaf's successor is node+1)
+        if (b == 0) { node = node + 1; continue; }        // inner: left child first
+        for (uint32_t k = 0; k < b; ++k) {                // leaf: Moeller-Trumbore, bvh.rs:91-138
+            const size_t ti = 3 * (size_t)(a + k);
+            const float4 r0 = t4[ti], r1 = t4[ti + 1], r2 = t4[ti + 2];
+            const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+            f3 hh = cross(rd, e2);
+            float aa = dot(e1, hh);
+            if (fabsf(aa) < EPS) continue;
+            float f = 1.0f / aa;
+            f3 s = ro - v0;
+            float u = f * dot(s, hh);
+            if (!(u >= 0.0f && u <= 1.0f)) continue;
+            f3 q = cross(s, e1);
+            float v = f * dot(rd, q);
+            if (v < 0.0f || u + v > 1.0f) continue;
+            float t = f * dot(e2, q);
+            if (t > t_min && t < best_t) { best_t = t; best_tri = a + k; }
+        }
+        node = node + 1;
+    }
+    if (best_tri == 0xFFFFFFFFu) return false;
+    const float4 r2 = t4[3 * (size_t)best_tri + 2];
+    f3 tn = mk(r2.y, r2.z, r2.w);
+    f3 pos_obj = ro + rd * best_t;
+    f3 n_obj = (dot(rd, tn) < 0.0f) ? tn : -tn;                         // bvh.rs:118-124
+    f3 pw = xform_o2w_point(pr, pos_obj);
+    f3 nw = normalized(xform_normal(pr, n_obj));
+    float t_world = best_t * len(rd_raw) / len(rd_w);                   // (sic) mesh_object.rs:312-314
+    if (t_world < t_min || t_world > t_max) return false;
+    h.t = t_world; h.p = pw;
+    set_face(h, rd_w, nw, pr->material);
+    return true;
+}
+
+// hittable.rs:45-58 -- HittableList::hit with t_min = EPSILON, t_max = INFINITY (renderer.rs:24)
+DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris,
+                  f3 ro, f3 rd, Hit& best) {
+    float closest = __builtin_inff();
+    bool any = false;
+    for (uint32_t i = 0; i < n_prims; ++i) {
+        cprim_t pr = prims + i;
+        Hit h; bool hit = false;
+        switch (pr->kind) {                               // wave-uniform: scalar branch
+            case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ro, rd, EPS, closest, h); break;
+            case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ro, rd, EPS, closest, h); break;
+            case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ro, rd, EPS, closest, h); break;
+            case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, ro, rd, EPS, closest, h); break;
+            default:                  hit = hit_mesh(pr, nodes, tris, ro, rd, EPS, closest, h); break;
+        }
+        if (hit) { closest = h.t; best = h; any = true; }
+    }
+    return any;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Materials
+// ---------------------------------------------------------------------------------------------------
+DI f3 mat_reflect(f3 v, f3 n) {                                                   // material.rs:194-206
+    if (has_nan(v)) return nan3();
+    if (has_nan(n) || is_zero(n)) return nan3();
+    return v - (n * 2.0f) * dot(v, n);
+}
+DI float powi5(float x) { return x * ((x * x) * (x * x)); }                       // llvm.powi.f32(x, 5)
+DI float schlick(float cosine, float ref_idx) {                                   // material.rs:221-227 == tungsten/materials.rs:23-27
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * powi5(1.0f - cosine);
+}
+DI f3 fresnel_conductor(float cos_theta, f3 eta, f3 k) {                          // tungsten/materials.rs:184-202
+    cos_theta = clamp01(cos_theta);
+    f3 cos2 = splat(cos_theta * cos_theta);
+    f3 sin2 = splat(1.0f) - cos2;
+    f3 eta2 = eta * eta, k2 = k * k;
+    f3 t0 = eta2 - k2 - sin2;
+    f3 a2plusb2 = sqrt3(t0 * t0 + splat(4.0f) * eta2 * k2);
+    f3 t1 = a2plusb2 + cos2;
+    f3 a = sqrt3((a2plusb2 + t0) * splat(0.5f));
+    f3 t2 = splat(2.0f * cos_theta) * a;
+    f3 rs = (t1 - t2) / (t1 + t2);
+    f3 t3 = cos2 * a2plusb2 + sin2 * sin2;
+    f3 rp = rs * ((t3 - t2) / (t3 + t2));
+    return (rs + rp) * splat(0.5f);
+}
+DI float ggx_g1(float n_dot_x, float roughness) {                                 // tungsten/materials.rs:205-216
+    if (n_dot_x <= 0.0f) return 0.0f;
+    float a = roughness * roughness;
+    float k = a / 2.0f;
+    float denom = n_dot_x * (1.0f - k) + k;
+    if (denom < EPS) return 1.0f;
+    return n_dot_x / denom;
+}
+DI float beckmann_lambda(float a, float x) {                                      // tungsten/materials.rs:225-232
+    float t = 1.0f / (a * x);
+    if (t < 1.6f) return (1.0f - 1.259f * t + 0.396f * t * t) / (3.535f * t + 2.181f * t * t);
+    return 0.0f;
+}
+
+// Result of one surface interaction (renderer.rs:26-36): either the path goes on (scattered ray +
+// attenuation) or it ends with `emitted` (scatter -> None).
+template <class Rng>
+DI bool surface_scatter(const DevMat* __restrict__ mats, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted) {
+    const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
+    const float4 q0 = m4[0];
+    const uint32_t kind = __float_as_uint(q0.x);
+    const f3 albedo = mk(q0.y, q0.z, q0.w);
+    const bool front_face = (h.mat_ff >> 31) != 0;
+    emitted = mk(0.f, 0.f, 0.f);
+    if (kind == MI355RT_MAT_EMISSIVE) { emitted = albedo; return false; }         // material.rs:179-191
+    if (kind == MI355RT_MAT_NULL) return false;                                   // material.rs:239-251
+    rng.begin_scatter();
+    bool diffuse = false;                                                          // Lambert-style bounce shared by 3 materials
+    atten = albedo;
+    if (kind == MI355RT_MAT_LAMBERT_SOLID) {                                       // material.rs:47-71
+        diffuse = true;
+    } else if (kind == MI355RT_MAT_LAMBERT_CHECKER) {                              // tungsten/materials.rs:89-99
+        const float4 q1 = m4[1];
+        float inv_scale = q1.w;
+        int32_t sum = (int32_t)((uint32_t)as_i32_sat(floorf(h.p.x * inv_scale)) + (uint32_t)as_i32_sat(floorf(h.p.y * inv_scale)) +
+                                (uint32_t)as_i32_sat(floorf(h.p.z * inv_scale)));
+        if ((sum & 1) != 0) atten = mk(q1.x, q1.y, q1.z);
+        diffuse = true;
+    } else if (kind == MI355RT_MAT_PLASTIC) {                                      // tungsten/materials.rs:29-65
+        float ior = m4[1].w;
+        float dn = dot(rd_in, h.n);
+        float cosine = (dn > 0.0f) ? ior * dn / len(rd_in) : -dn / len(rd_in);
+        float reflect_prob = schlick(cosine, ior);
+        if (rng.uniform01_0() < reflect_prob) {
+            f3 reflected = normalized(rd_in - (h.n * 2.0f) * dot(rd_in, h.n));     // Vec3::reflect, vec3.rs:68-70
+            new_o = h.p + h.n * EPS;
+            new_d = normalized(reflected);                                         // Ray::new
+            atten = mk(0.9f, 0.9f, 0.9f);
+        } else {
+            diffuse = true;
+        }
+    } else if (kind == MI355RT_MAT_METAL) {                                        // material.rs:87-110
+        float fuzz = m4[1].w;
+        f3 reflected = mat_reflect(normalized(rd_in), h.n);
+        f3 fuzzed = reflected;
+        if (fuzz > 0.0f) {
+            f3 p; uint32_t j = 0;
+            do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));          // vec3.rs:54-61
+            fuzzed = reflected + p * fuzz;
+        }
+        if (!(dot(fuzzed, h.n) > 0.0f)) return false;
+        new_o = h.p + h.n * EPS;
+        new_d = normalized(normalized(fuzzed));
+    } else if (kind == MI355RT_MAT_DIELECTRIC) {                                   // material.rs:122-162
+        float ri = m4[1].w;
+        float ratio = front_face ? (1.0f / ri) : (ri / 1.0f);
+        f3 unit = normalized(rd_in);
+        float cos_theta = fminf(dot(-unit, h.n), 1.0f);
+        float sin2 = 1.0f - cos_theta * cos_theta;
+        bool cannot_refract = ratio * ratio * sin2 > 1.0f;
+        float reflectance = schlick(cos_theta, 1.0f / ratio);
+        f3 dir;
+        if (cannot_refract || reflectance > rng.uniform01_0()) {                   // no draw under TIR (material.rs:145)
+            dir = mat_reflect(unit, h.n);
+        } else {                                                                   // refract(), material.rs:208-219
+            float ct = fminf(dot(-unit, h.n), 1.0f);
+            f3 perp = (unit + h.n * ct) * ratio;
+            float par2 = 1.0f - len2(perp);
+            dir = (par2 < 0.0f) ? mat_reflect(unit, h.n) : perp + h.n * (-sqrtf(par2));
+        }
+        new_o = (dot(dir, h.n) > 0.0f) ? h.p + h.n * EPS : h.p - h.n * EPS;
+        new_d = normalized(normalized(dir));
+        atten = mk(1.f, 1.f, 1.f);
+    } else {                                                                       // RoughConductor, tungsten/materials.rs:306-377
+        const bool ggx = (kind == MI355RT_MAT_ROUGH_GGX);
+        if (has_nan(rd_in)) return false;
+        if (has_nan(h.n) || is_zero(h.n)) return false;
+        f3 n = h.n;
+        f3 v = -normalized(rd_in);
+        if (has_nan(v)) return false;
+        const float4 q1 = m4[1], q2 = m4[2], q3 = m4[3];
+        float rough = q1.w;
+        f3 eta = mk(q2.y, q2.z, q2.w), kk = mk(q3.x, q3.y, q3.z);
+        // sample_ggx / sample_beckmann, tungsten/materials.rs:236-290
+        float u1 = fmaxf(rng.uniform01_0(), 1e-6f);
+        float u2 = rng.uniform01_1();
+        float theta_arg;
+        if (ggx) { float a = rough * rough; theta_arg = a * a * (-logf(u1)) / (1.0f - u1); }
+        else { theta_arg = -(rough * rough * logf(u1)); }
+        f3 hv;
+        if ((theta_arg != theta_arg) || isinf(theta_arg) || theta_arg < 0.0f) {
+            hv = to_world(mk(0.f, 0.f, 1.f), n);
+        } else {
+            float theta = atanf(sqrtf(theta_arg));
+            float phi = 2.0f * PI_F * u2;
+            float st = sinf(theta), ct = cosf(theta);
+            f3 hl = mk(st * cosf(phi), st * sinf(phi), ct);
+            hv = has_nan(hl) ? to_world(mk(0.f, 0.f, 1.f), n) : to_world(hl, n);
+        }
+        if (has_nan(hv)) return false;
+        f3 l = mat_reflect(-v, hv);
+        if (has_nan(l)) return false;
+        if (dot(l, n) <= 0.0f) return false;
+        float n_dot_l = fmaxf(dot(n, l), 0.0f), n_dot_v = fmaxf(dot(n, v), 0.0f);
+        float n_dot_h = fmaxf(dot(n, hv), 0.0f), v_dot_h = fmaxf(dot(v, hv), 0.0f);
+        float g = ggx ? ggx_g1(n_dot_v, rough) * ggx_g1(n_dot_l, rough)
+                      : 1.0f / (1.0f + beckmann_lambda(rough, n_dot_v) + beckmann_lambda(rough, n_dot_l));
+        f3 f = fresnel_conductor(v_dot_h, eta, kk);
+        f3 num = f * g * v_dot_h;
+        float den = n_dot_v * n_dot_h + EPS;
+        atten = (den > EPS) ? albedo * divf(num, den) : mk(0.f, 0.f, 0.f);
+        new_o = h.p + n * EPS;
+        new_d = normalized(normalized(l));
+    }
+    if (diffuse) {                                                                 // material.rs:54-62
+        f3 p; uint32_t j = 0;
+        do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));              // vec3.rs:54-61
+        f3 dir = h.n + normalized(p);
+        if (near_zero(dir)) dir = h.n;
+        new_o = h.p + h.n * EPS;
+        new_d = normalized(normalized(dir));                                       // .normalized() then Ray::new
+    }
+    return true;
+}
+
+// camera.rs:33-42 + ray.rs:12-17
+DI void camera_ray(const DevCamera& cam, float u, float v, f3& ro, f3& rd) {
+    float ndc_x = 2.0f * u - 1.0f;
+    float ndc_y = 1.0f - 2.0f * v;
+    f3 right = mk(cam.right[0], cam.right[1], cam.right[2]), up = mk(cam.true_up[0], cam.true_up[1], cam.true_up[2]);
+    f3 offset = right * (ndc_x * cam.half_width) + up * (ndc_y * cam.half_height);
+    f3 dir = normalized(mk(cam.forward[0], cam.forward[1], cam.forward[2]) + offset);
+    ro = mk(cam.position[0], cam.position[1], cam.position[2]);
+    rd = normalized(dir);
+}
+
+DI uint32_t mbcnt64(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
+DI uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ===================================================================================================
+// k_render_ctr -- persistent, path-regenerating wave64 path tracer
+// ===================================================================================================
+__global__ void __launch_bounds__(BLOCK_THREADS) k_render_ctr(const RenderParams P) {
+    cprim_t prims = (cprim_t)(P.prims);
+    const uint32_t lane = threadIdx.x & 63u;
+
+    // wave-uniform work cursor: [b_next, b_end) are unclaimed sample indices of the wave's current batch
+    uint32_t b_next = 0, b_end = 0;
+    bool no_more = false;
+
+    // per-lane path state
+    bool active = false;
+    uint32_t sidx = 0;              // band-local sample index (where the radiance goes)
+    uint32_t ray_index = 0;         // rays already traced on this path
+    f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1), thr = mk(1, 1, 1);
+    RngCtr rng; rng.k0 = rng.k1 = rng.x = rng.s = rng.ray = 0; rng.b0[0] = rng.b0[1] = rng.b0[2] = rng.b0[3] = 0;
+    uint32_t n_paths = 0, n_rays = 0;
+    float4* __restrict__ radiance = reinterpret_cast<float4*>(P.radiance);
+
+    for (;;) {
+        // ---- path regeneration: deal unclaimed samples to idle lanes (ballot + mbcnt compaction) ----
+        const uint64_t idle = __ballot(!active);
+        if (idle != 0ull) {
+            if (b_next == b_end && !no_more) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(P.batch_counter, 1u);
+                b = __builtin_amdgcn_readfirstlane(b);
+                if (b >= P.n_batches) { no_more = true; }
+                else { b_next = b * BATCH_SAMPLES; b_end = min(b_next + BATCH_SAMPLES, P.band_samples); }
+            }
+            const uint32_t avail = b_end - b_next;
+            const uint32_t take = min((uint32_t)__popcll(idle), avail);
+            if (take != 0u) {
+                const uint32_t rank = mbcnt64(idle);
+                if (!active && rank < take) {
+                    sidx = b_next + rank;
+                    const uint32_t pix_local = sidx / P.spp;
+                    const uint32_t s = sidx - pix_local * P.spp;
+                    const uint32_t pix = P.band_pixel0 + pix_local;
+                    const uint32_t jrow = pix / P.width;
+                    const uint32_t x = pix - jrow * P.width;
+                    const uint32_t y = P.rows[jrow];
+                    const uint64_t ykey = (uint64_t)y + (((uint64_t)P.seed_hi << 32) | (uint64_t)P.seed_lo);
+                    rng.start((uint32_t)ykey, (uint32_t)(ykey >> 32), x, s);
+                    const float u = ((float)x + rng.jitter_u()) / (float)P.width;    // renderer.rs:96
+                    const float v = ((float)y + rng.jitter_v()) / (float)P.height;   // renderer.rs:97
+                    camera_ray(P.cam, u, v, ro, rd);                                 // renderer.rs:99
+                    thr = mk(1.f, 1.f, 1.f);
+                    ray_index = 0;
+                    active = true;
+                    ++n_paths;
+                }
+                b_next += take;
+            }
+            if (__ballot(active) == 0ull) { if (no_more) break; else continue; }
+        }
+
+        // ---- one trace_ray level (renderer.rs:19-65) for every live lane ----
+        if (active) {
+            f3 term = mk(0.f, 0.f, 0.f);
+            bool done = false;
+            if (ray_index == P.max_depth) {                       // depth == 0 -> Color::BLACK (renderer.rs:20-22)
+                done = true;
+            } else {
+                ++n_rays;
+                Hit h;
+                if (!hit_scene(prims, P.n_prims, P.nodes, P.tris, ro, rd, h)) {
+                    term = mk(P.miss[0], P.miss[1], P.miss[2]);  // renderer.rs:61
+                    done = true;
+                } else {
+                    f3 no, nd, atten, emitted;
+                    if (surface_scatter(P.mats, h, rd, rng, no, nd, atten, emitted)) {
+                        thr = thr * atten; ro = no; rd = nd; ++ray_index;
+                    } else {
+                        term = emitted; done = true;              // renderer.rs:35
+                    }
+                }
+            }
+            if (done) {
+                const f3 L = thr * term;
+                radiance[sidx] = make_float4(L.x, L.y, L.z, 0.0f);
+                active = false;
+            }
+        }
+    }
+    const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
+    if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }
+}
+
+// ===================================================================================================
+// k_resolve -- ordered per-pixel sum, 1/spp, sqrt gamma, pack (renderer.rs:100-120)
+// ===================================================================================================
+__global__ void __launch_bounds__(256) k_resolve(const ResolveParams P) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.band_pixels) return;
+    const float4* __restrict__ r = reinterpret_cast<const float4*>(P.radiance) + (size_t)p * P.spp;
+    f3 acc = mk(0.f, 0.f, 0.f);
+    for (uint32_t s = 0; s < P.spp; ++s) { const float4 v = r[s]; acc = acc + mk(v.x, v.y, v.z); }
+    const f3 pixel = acc * P.inv_spp;
+    const size_t o = (size_t)P.band_pixel0 + p;
+    if (P.out_linear) { P.out_linear[3 * o] = pixel.x; P.out_linear[3 * o + 1] = pixel.y; P.out_linear[3 * o + 2] = pixel.z; }
+    P.out_packed[o] = color_to_u32(sqrt3(pixel));
+}
+
+// ===================================================================================================
+// k_render_ref -- validation: replay of the reference's per-row sequential stream, one lane per row
+// ===================================================================================================
+__global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
+    cprim_t prims = (cprim_t)(P.prims);
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n_rows) return;
+    const uint32_t y = P.rows[j];
+    RngRef rng;
+    rng.seed_from_u64((uint64_t)y + (((uint64_t)P.seed_hi << 32) | (uint64_t)P.seed_lo));      // renderer.rs:91
+    float* __restrict__ stack = P.fold_stack + (size_t)j * P.max_depth * 3;
+    const float inv_spp = 1.0f / (float)P.spp;                                                  // renderer.rs:85
+    unsigned long long n_rays = 0;
+    for (uint32_t x = 0; x < P.width; ++x) {                                                    // renderer.rs:93
+        f3 acc = mk(0.f, 0.f, 0.f);
+        for (uint32_t s = 0; s < P.spp; ++s) {                                                  // renderer.rs:95
+            const float u = ((float)x + rng.jitter_u()) / (float)P.width;
+            const float v = ((float)y + rng.jitter_v()) / (float)P.height;
+            f3 ro, rd; camera_ray(P.cam, u, v, ro, rd);
+            f3 term = mk(0.f, 0.f, 0.f);
+            uint32_t depth = 0;
+            for (;;) {
+                if (depth == P.max_depth) break;
+                ++n_rays;
+                Hit h;
+                if (!hit_scene(prims, P.n_prims, P.nodes, P.tris, ro, rd, h)) { term = mk(P.miss[0], P.miss[1], P.miss[2]); break; }
+                f3 no, nd, atten, emitted;
+                if (!surface_scatter(P.mats, h, rd, rng, no, nd, atten, emitted)) { term = emitted; break; }
+                stack[3 * depth] = atten.x; stack[3 * depth + 1] = atten.y; stack[3 * depth + 2] = atten.z;
+                ro = no; rd = nd; ++depth;
+            }
+            f3 L = term;                                                                        // fold tail-first: emitted + atten * scattered (renderer.rs:33)
+            for (uint32_t d = depth; d-- > 0;) L = mk(0.f, 0.f, 0.f) + mk(stack[3 * d], stack[3 * d + 1], stack[3 * d + 2]) * L;
+            acc = acc + L;                                                                      // renderer.rs:100-101
+        }
+        const f3 pixel = acc * inv_spp;                                                         // renderer.rs:103
+        const size_t o = (size_t)j * P.width + x;
+        if (P.out_linear) { P.out_linear[3 * o] = pixel.x; P.out_linear[3 * o + 1] = pixel.y; P.out_linear[3 * o + 2] = pixel.z; }
+        P.out_packed[o] = color_to_u32(sqrt3(pixel));
+    }
+    if (P.stats) { atomicAdd(&P.stats[0], (unsigned long long)P.width * P.spp); atomicAdd(&P.stats[1], n_rays); }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+int launch_render_ctr(const RenderParams& p, uint32_t grid_blocks, void* stream) {
+    hipLaunchKernelGGL(k_render_ctr, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+int launch_resolve(const ResolveParams& p, void* stream) {
+    const uint32_t blocks = (p.band_pixels + 255u) / 256u;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+int launch_render_ref(const RefParams& p, void* stream) {
+    const uint32_t blocks = (p.n_rows + 63u) / 64u;
+    hipLaunchKernelGGL(k_render_ref, dim3(blocks), dim3(64), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+int query_render_ctr_occupancy(int* blocks_per_cu, int* vgprs, int* sgprs) {
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_ctr, BLOCK_THREADS, 0);
+    if (e != hipSuccess) return (int)e;
+    hipFuncAttributes fa;
+    e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_render_ctr));
+    if (e != hipSuccess) return (int)e;
+    *blocks_per_cu = nb; *vgprs = fa.numRegs; *sgprs = 0;
+    return 0;
+}
+
+}  // namespace mi355rt

@@ -1,0 +1,113 @@
+"""ctypes binding of libmi355rt.so -- the HIP path behind the C ABI (include/mi355rt.h).
+
+There is no CPU fallback: `lib()` raises if the HIP library has not been built, and every render call
+raises if no GPU is visible.  torch is NOT needed here; callers that hold torch tensors pass
+`tensor.data_ptr()` and `torch.cuda.current_stream().cuda_stream`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi, build
+
+EXPORTS = ["mi355rt_render", "mi355rt_context_create", "mi355rt_context_destroy", "mi355rt_context_set_scene",
+           "mi355rt_rows_selected", "mi355rt_context_render", "mi355rt_last_error", "mi355rt_abi_version"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(build.DEVICE_SO):
+            raise RuntimeError(f"{build.DEVICE_SO} is missing: the HIP extension must be built "
+                               "(__graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(build.DEVICE_SO)
+        L.mi355rt_last_error.restype = C.c_char_p
+        L.mi355rt_abi_version.restype = C.c_uint32
+        L.mi355rt_render.restype = C.c_int
+        L.mi355rt_render.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(abi.Settings),
+                                     C.POINTER(abi.Options), C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
+        L.mi355rt_context_create.restype = C.c_int
+        L.mi355rt_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.mi355rt_context_destroy.argtypes = [C.c_void_p]
+        L.mi355rt_context_set_scene.restype = C.c_int
+        L.mi355rt_context_set_scene.argtypes = [C.c_void_p, C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(abi.Settings)]
+        L.mi355rt_rows_selected.restype = C.c_int
+        L.mi355rt_rows_selected.argtypes = [C.POINTER(abi.Settings), C.POINTER(abi.Options), C.POINTER(C.c_uint32)]
+        L.mi355rt_context_render.restype = C.c_int
+        L.mi355rt_context_render.argtypes = [C.c_void_p, C.POINTER(abi.Options), C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.POINTER(abi.Stats)]
+        if L.mi355rt_abi_version() != abi.ABI_VERSION:
+            raise RuntimeError("libmi355rt.so ABI version does not match abi.py")
+        _lib = L
+    return _lib
+
+
+class RenderError(RuntimeError):
+    def __init__(self, what, rc):
+        super().__init__(f"{what} failed ({rc}): {lib().mi355rt_last_error().decode()}")
+        self.rc = rc
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RenderError(what, rc)
+
+
+def render(scene, camera, settings, options=None, want_linear=True, want_stats=True):
+    """One-shot mi355rt_render with host buffers (what src/main.rs:57 would call).
+    Returns (packed u32 [rows, W], linear f32 [rows, W, 3] or None, abi.Stats or None)."""
+    sc = getattr(scene, "c", scene)
+    rows = len(abi.rows_selected(settings.height, options))
+    W = settings.width
+    packed = np.zeros((rows, W), np.uint32)
+    linear = np.zeros((rows, W, 3), np.float32) if want_linear else None
+    stats = abi.Stats() if want_stats else None
+    _check(lib().mi355rt_render(C.byref(sc), C.byref(camera), C.byref(settings),
+                                C.byref(options) if options is not None else None,
+                                packed.ctypes.data, linear.ctypes.data if want_linear else None,
+                                C.byref(stats) if want_stats else None), "mi355rt_render")
+    return packed, linear, stats
+
+
+class Context:
+    """Resident-scene API: upload once, render many times into DEVICE buffers."""
+
+    def __init__(self, hip_device=0):
+        self._h = C.c_void_p()
+        _check(lib().mi355rt_context_create(hip_device, C.byref(self._h)), "mi355rt_context_create")
+        self.settings = None
+
+    def set_scene(self, scene, camera, settings):
+        sc = getattr(scene, "c", scene)
+        _check(lib().mi355rt_context_set_scene(self._h, C.byref(sc), C.byref(camera), C.byref(settings)),
+               "mi355rt_context_set_scene")
+        self.settings = abi.Settings(settings.width, settings.height, settings.samples_per_pixel, settings.max_depth)
+
+    def rows_selected(self, options=None):
+        n = C.c_uint32()
+        _check(lib().mi355rt_rows_selected(C.byref(self.settings), C.byref(options) if options is not None else None,
+                                           C.byref(n)), "mi355rt_rows_selected")
+        return n.value
+
+    def render(self, d_out_packed, d_out_linear=None, options=None, stream=None, want_stats=False):
+        """d_out_*: integer device addresses (e.g. torch tensor .data_ptr()); stream: hipStream_t handle or None."""
+        stats = abi.Stats() if want_stats else None
+        _check(lib().mi355rt_context_render(self._h, C.byref(options) if options is not None else None,
+                                            C.c_void_p(d_out_packed), C.c_void_p(d_out_linear) if d_out_linear else None,
+                                            C.c_void_p(stream) if stream else None,
+                                            C.byref(stats) if want_stats else None), "mi355rt_context_render")
+        return stats
+
+    def close(self):
+        if self._h:
+            lib().mi355rt_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
