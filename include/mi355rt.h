@@ -205,6 +205,14 @@ int  mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* options
                             void* d_out_packed_rgb, void* d_out_linear_rgb_or_null,
                             void* hip_stream, mi355rt_stats* stats_or_null);
 
+/* Kernel timing without extra synchronisation: while enabled, every mi355rt_context_render call that
+ * passes stats == NULL records HIP events around its kernels on the caller's stream.  After the
+ * caller has synchronised that stream, read_timing returns the summed kernel durations and the
+ * number of (path tracing + resolve) launch pairs since the last read, and resets the pool.        */
+int  mi355rt_context_set_timing(mi355rt_context* ctx, int enable);
+int  mi355rt_context_read_timing(mi355rt_context* ctx, double* render_kernel_ms, double* resolve_kernel_ms,
+                                 uint32_t* launches);
+
 const char* mi355rt_last_error(void);
 uint32_t    mi355rt_abi_version(void);
 

@@ -27,6 +27,10 @@ import numpy as np
 from . import abi
 
 F = np.float32
+_libm = C.CDLL("libm.so.6")
+_libm.tanf.restype = C.c_float
+_libm.tanf.argtypes = [C.c_float]
+_tanf = _libm.tanf
 EPSILON = F(1e-4)
 PI_F = F(math.pi)
 
@@ -150,7 +154,7 @@ def camera_new(position, look_at, world_up, fov, aspect):
     right = normalized(cross(forward, normalized(world_up)))
     true_up = normalized(cross(right, forward))
     fov_rad = F(F(F(fov) * PI_F) / F(180.0))
-    half_height = F(math.tan(float(F(fov_rad / F(2.0)))))     # tanf; f64 tan rounded to f32
+    half_height = F(_tanf(float(F(fov_rad / F(2.0)))))         # f32::tan -> libm tanf
     half_width = F(half_height * F(aspect))
     cam = abi.Camera()
     cam.position[:] = [float(v) for v in position]

@@ -78,7 +78,17 @@ struct mi355rt_context {
     DevBuf<uint32_t> rows; DevBuf<float> radiance; DevBuf<uint32_t> counters; DevBuf<unsigned long long> stats;
     DevBuf<float> fold_stack;
     std::vector<uint32_t> rows_host;     // source of the async row-table upload; must outlive the copy
+    bool rows_valid = false;             // ctx->rows already holds rows_host (same selection as the last call)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // timing pool (mi355rt_context_set_timing): event triples recorded around every kernel pair without
+    // synchronising; mi355rt_context_read_timing sums them after the caller's own stream sync.
+    bool timing = false;
+    std::vector<hipEvent_t> pool; size_t pool_used = 0;
+    uint32_t timed_launches = 0;
+    hipEvent_t pool_get() {
+        if (pool_used == pool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+        return pool[pool_used++];
+    }
 };
 
 namespace {
@@ -228,6 +238,7 @@ void mi355rt_context_destroy(mi355rt_context* ctx) {
     ctx->prims.release(); ctx->mats.release(); ctx->nodes.release(); ctx->tris.release(); ctx->rows.release();
     ctx->radiance.release(); ctx->counters.release(); ctx->stats.release(); ctx->fold_stack.release();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->pool) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -237,7 +248,7 @@ int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, 
     if (!camera) return fail(MI355RT_ERR_INVALID, "camera is null");
     int rc = check_settings(settings); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    ctx->have_scene = false;
+    ctx->have_scene = false; ctx->rows_valid = false;
     rc = build_device_scene(ctx, scene); if (rc) return rc;
     static_assert(sizeof(DevCamera) == sizeof(mi355rt_camera), "camera layout is shared with the ABI");
     std::memcpy(&ctx->cam, camera, sizeof(DevCamera));
@@ -254,16 +265,23 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
     hipStream_t stream = (hipStream_t)hip_stream;
     const mi355rt_settings& st = ctx->settings;
     RowSel sel; int rc = select_rows(st, opt, sel); if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(stream));   // the previous call's row-table upload may still read rows_host
-    ctx->rows_host.swap(sel.rows);
+    const bool same_rows = ctx->rows_valid && sel.rows == ctx->rows_host;
+    if (!same_rows) {
+        HIP_TRY(hipStreamSynchronize(stream));   // a previous call's row-table upload may still read rows_host
+        ctx->rows_host.swap(sel.rows);
+        ctx->rows_valid = false;
+    }
     const uint32_t rng_mode = opt ? opt->rng_mode : (uint32_t)MI355RT_RNG_CTR;
     const uint64_t seed = opt ? opt->seed : 0;
     const uint32_t n_rows = (uint32_t)ctx->rows_host.size();
     if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
     if (n_rows == 0) return MI355RT_OK;
 
-    if ((rc = ctx->rows.ensure(n_rows))) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->rows.p, ctx->rows_host.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    if (!same_rows) {
+        if ((rc = ctx->rows.ensure(n_rows))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->rows.p, ctx->rows_host.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        ctx->rows_valid = true;
+    }
     if ((rc = ctx->stats.ensure(2))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, 2 * sizeof(unsigned long long), stream));
 
@@ -324,10 +342,15 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
             const uint32_t grid = std::max(1u, std::min(resident, (p.n_batches + waves_per_block - 1) / waves_per_block));
             grid_blocks = std::max(grid_blocks, grid);
             r.band_pixel0 = (uint32_t)p0; r.band_pixels = (uint32_t)np;
+            hipEvent_t pe0 = nullptr, pe1 = nullptr, pe2 = nullptr;
+            if (ctx->timing && !stats) { pe0 = ctx->pool_get(); pe1 = ctx->pool_get(); pe2 = ctx->pool_get(); if (!pe0 || !pe1 || !pe2) return fail(MI355RT_ERR_HIP, "event pool"); }
             if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], stream));
+            if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
             if (launch_render_ctr(p, grid, stream) != 0) return fail(MI355RT_ERR_HIP, "k_render_ctr launch failed");
             if (stats) HIP_TRY(hipEventRecord(ctx->ev[1], stream));
+            if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
             if (launch_resolve(r, stream) != 0) return fail(MI355RT_ERR_HIP, "k_resolve launch failed");
+            if (pe2) { HIP_TRY(hipEventRecord(pe2, stream)); ++ctx->timed_launches; }
             if (stats) {
                 HIP_TRY(hipEventRecord(ctx->ev[2], stream));
                 HIP_TRY(hipEventSynchronize(ctx->ev[2]));
@@ -346,6 +369,30 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         stats->samples = h[0]; stats->rays = h[1];
         stats->bands = n_bands; stats->grid_blocks = grid_blocks; stats->block_threads = block_threads;
     }
+    return MI355RT_OK;
+}
+
+int mi355rt_context_set_timing(mi355rt_context* ctx, int enable) {
+    if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
+    ctx->timing = enable != 0; ctx->pool_used = 0; ctx->timed_launches = 0;
+    return MI355RT_OK;
+}
+
+int mi355rt_context_read_timing(mi355rt_context* ctx, double* render_kernel_ms, double* resolve_kernel_ms, uint32_t* launches) {
+    if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double a = 0, c = 0;
+    for (size_t i = 0; i + 2 < ctx->pool_used; i += 3) {
+        HIP_TRY(hipEventSynchronize(ctx->pool[i + 2]));
+        float x = 0, y = 0;
+        HIP_TRY(hipEventElapsedTime(&x, ctx->pool[i], ctx->pool[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&y, ctx->pool[i + 1], ctx->pool[i + 2]));
+        a += x; c += y;
+    }
+    if (render_kernel_ms) *render_kernel_ms = a;
+    if (resolve_kernel_ms) *resolve_kernel_ms = c;
+    if (launches) *launches = ctx->timed_launches;
+    ctx->pool_used = 0; ctx->timed_launches = 0;
     return MI355RT_OK;
 }
 

@@ -1,0 +1,91 @@
+// mesh_io.cpp -- Mesh::from_obj / Mesh::from_wo3 (src/mesh/mesh_object.rs:59-259) + Triangle::new
+// (src/mesh/triangle.rs:14-25): file -> object-space triangle soup in file order.
+//
+// tobj 4.0.3 (Cargo.lock pin, not under /root/reference) is restated for what from_obj consumes:
+// `v` positions and `f` faces, faces fan-triangulated from their first vertex (GPU_LOAD_OPTIONS =
+// triangulate + single_index; single_index may renumber vertices but never changes a corner's position).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "host_common.hpp"
+#include "mesh_io.hpp"
+#include "xform.hpp"
+
+namespace mi355rt_host {
+
+// Triangle::new + the degenerate filter |cross|^2 < EPSILON^2 (mesh_object.rs:128-134, :223-235)
+static bool make_triangle(V3 v0, V3 v1, V3 v2, mi355rt_triangle& out) {
+    const V3 e1 = v1 - v0, e2 = v2 - v0;
+    const V3 c = cross(e1, e2);
+    const V3 n = normalized(c);
+    out = {{v0.x, v0.y, v0.z}, {v1.x, v1.y, v1.z}, {v2.x, v2.y, v2.z}, {n.x, n.y, n.z}};
+    return !(dot(c, c) < EPSILON * EPSILON);
+}
+
+int load_obj(const std::string& path, std::vector<mi355rt_triangle>& tris) {
+    std::ifstream f(path);
+    if (!f) return set_error(MI355RT_ERR_IO, "cannot open OBJ " + path);
+    std::vector<V3> verts;
+    std::vector<long> face;
+    std::string line;
+    while (std::getline(f, line)) {
+        const char* s = line.c_str();
+        while (*s == ' ' || *s == '\t') ++s;
+        if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+            double x = 0, y = 0, z = 0;
+            if (std::sscanf(s + 1, "%lf %lf %lf", &x, &y, &z) == 3) verts.push_back({(float)x, (float)y, (float)z});
+        } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+            face.clear();
+            std::istringstream ss(s + 1);
+            std::string tok;
+            while (ss >> tok) {
+                long i = std::strtol(tok.c_str(), nullptr, 10);            // "a", "a/b", "a/b/c", "a//c"
+                face.push_back(i > 0 ? i - 1 : (long)verts.size() + i);
+            }
+            for (size_t k = 1; k + 1 < face.size(); ++k) {
+                const long a = face[0], b = face[k], c = face[k + 1];
+                const long n = (long)verts.size();
+                if (a < 0 || b < 0 || c < 0 || a >= n || b >= n || c >= n) continue;   // mesh_object.rs:114-119
+                mi355rt_triangle t;
+                if (make_triangle(verts[a], verts[b], verts[c], t)) tris.push_back(t);
+            }
+        }
+    }
+    return MI355RT_OK;
+}
+
+// Mesh::from_wo3 INCLUDING its index-stride bug: the file stores 4 u32 per
+// triangle (v0, v1, v2, material); the reference reads 3 u32 per iteration for num_tris iterations
+// (mesh_object.rs:190-192), i.e. it consumes the first 3/4 of the index stream with a sliding phase.
+int load_wo3(const std::string& path, std::vector<mi355rt_triangle>& tris) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return set_error(MI355RT_ERR_IO, "cannot open WO3 " + path);
+    std::vector<unsigned char> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    auto rd_u64 = [&](size_t off, uint64_t& v) { if (off + 8 > b.size()) return false; std::memcpy(&v, b.data() + off, 8); return true; };
+    uint64_t nv = 0, nt = 0;
+    if (!rd_u64(0, nv)) return set_error(MI355RT_ERR_IO, "WO3 truncated header");
+    const size_t voff = 8;
+    if (nv > (b.size() - voff) / 32) return set_error(MI355RT_ERR_IO, "WO3 truncated vertices");
+    const size_t toff = voff + (size_t)nv * 32;
+    if (!rd_u64(toff, nt)) return set_error(MI355RT_ERR_IO, "WO3 truncated triangle header");
+    const size_t ioff = toff + 8;
+    if (nt > (b.size() - ioff) / 12) return set_error(MI355RT_ERR_IO, "WO3 truncated indices");   // read_u32 would hit EOF -> Err
+    std::vector<V3> verts((size_t)nv);
+    for (size_t i = 0; i < (size_t)nv; ++i) {
+        float p[3]; std::memcpy(p, b.data() + voff + i * 32, 12);      // position, then normal(3) + uv(2) skipped
+        verts[i] = {p[0], p[1], p[2]};
+    }
+    for (size_t i = 0; i < (size_t)nt; ++i) {
+        uint32_t id[3]; std::memcpy(id, b.data() + ioff + i * 12, 12);
+        if (id[0] >= nv || id[1] >= nv || id[2] >= nv) continue;         // mesh_object.rs:202-214
+        mi355rt_triangle t;
+        if (make_triangle(verts[id[0]], verts[id[1]], verts[id[2]], t)) tris.push_back(t);
+    }
+    return MI355RT_OK;
+}
+
+}  // namespace mi355rt_host

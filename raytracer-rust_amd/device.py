@@ -12,7 +12,8 @@ import numpy as np
 from . import abi, build
 
 EXPORTS = ["mi355rt_render", "mi355rt_context_create", "mi355rt_context_destroy", "mi355rt_context_set_scene",
-           "mi355rt_rows_selected", "mi355rt_context_render", "mi355rt_last_error", "mi355rt_abi_version"]
+           "mi355rt_rows_selected", "mi355rt_context_render", "mi355rt_context_set_timing", "mi355rt_context_read_timing",
+           "mi355rt_last_error", "mi355rt_abi_version"]
 
 _lib = None
 
@@ -39,6 +40,10 @@ def lib():
         L.mi355rt_context_render.restype = C.c_int
         L.mi355rt_context_render.argtypes = [C.c_void_p, C.POINTER(abi.Options), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.POINTER(abi.Stats)]
+        L.mi355rt_context_set_timing.restype = C.c_int
+        L.mi355rt_context_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.mi355rt_context_read_timing.restype = C.c_int
+        L.mi355rt_context_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         if L.mi355rt_abi_version() != abi.ABI_VERSION:
             raise RuntimeError("libmi355rt.so ABI version does not match abi.py")
         _lib = L
@@ -100,6 +105,15 @@ class Context:
                                             C.c_void_p(stream) if stream else None,
                                             C.byref(stats) if want_stats else None), "mi355rt_context_render")
         return stats
+
+    def set_timing(self, enable=True):
+        _check(lib().mi355rt_context_set_timing(self._h, 1 if enable else 0), "mi355rt_context_set_timing")
+
+    def read_timing(self):
+        """(render_kernel_ms, resolve_kernel_ms, launches) summed since the last read; call after syncing the stream."""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint32()
+        _check(lib().mi355rt_context_read_timing(self._h, C.byref(a), C.byref(b), C.byref(n)), "mi355rt_context_read_timing")
+        return a.value, b.value, n.value
 
     def close(self):
         if self._h:
