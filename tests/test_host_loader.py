@@ -1,0 +1,93 @@
+"""The product's C++ loader (csrc/host) against the independent numpy restatement (oracle/scene_loader.py):
+both follow src/tungsten/parser.rs and must produce bit-identical POD arrays."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+
+def _bytes(ptr, n, T):
+    if n == 0:
+        return np.zeros((0,), np.uint8)
+    return np.frombuffer((T * n).from_address(C.addressof(ptr.contents)), dtype=np.uint8).reshape(n, C.sizeof(T)).copy()
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_cpp_loader_equals_oracle_loader(name, native, abi):
+    host, _ = native
+    from oracle import scene_loader
+    kw = dict(skip_unknown_primitives=(name == "teapot"))
+    a = host.LoadedScene(SCENES[name], **kw)
+    b = scene_loader.load_scene(SCENES[name], **kw)
+    for f, _ in a.settings._fields_:
+        assert getattr(a.settings, f) == getattr(b.settings, f)
+    assert np.array_equal(np.frombuffer(a.camera, np.uint8), np.frombuffer(b.camera, np.uint8))
+    sa, sb = a.c, b.c
+    assert (sa.n_primitives, sa.n_materials, sa.n_meshes, sa.n_triangles) == (sb.n_primitives, sb.n_materials, sb.n_meshes, sb.n_triangles)
+    assert np.array_equal(_bytes(sa.primitives, sa.n_primitives, abi.Primitive), _bytes(sb.primitives, sb.n_primitives, abi.Primitive))
+    assert np.array_equal(_bytes(sa.materials, sa.n_materials, abi.Material), _bytes(sb.materials, sb.n_materials, abi.Material))
+    assert np.array_equal(_bytes(sa.triangles, sa.n_triangles, abi.Triangle), _bytes(sb.triangles, sb.n_triangles, abi.Triangle))
+    assert list(sa.miss_color) == [0.5, 0.5, 0.5]
+
+
+def test_scene_inventory_matches_survey(native, abi):
+    host, _ = native
+    c = host.LoadedScene(SCENES["cornell"])
+    kinds = [c.c.primitives[i].kind for i in range(c.c.n_primitives)]
+    assert kinds == [abi.PRIM_QUAD] * 5 + [abi.PRIM_CUBE] * 2 + [abi.PRIM_QUAD]       # JSON order = hit order (hittable.rs:50)
+    light = c.c.materials[c.c.primitives[7].material]
+    assert light.kind == abi.MAT_EMISSIVE and list(light.albedo) == [17.0, 12.0, 4.0]   # quad.emission wins over bsdf (parser.rs:707-711)
+    assert (c.settings.width, c.settings.height, c.settings.samples_per_pixel, c.settings.max_depth) == (1024, 1024, 64, 64)
+    v = host.LoadedScene(SCENES["veach"])
+    r = [v.c.primitives[i].data[3] for i in range(v.c.n_primitives) if v.c.primitives[i].kind == abi.PRIM_SPHERE]
+    assert r == pytest.approx([1.0, 0.5, 0.05])                                           # radius <- scale fallback (parser.rs:550-564)
+    em = [v.c.materials[v.c.primitives[i].material].albedo[0] for i in range(v.c.n_primitives) if v.c.primitives[i].kind == abi.PRIM_SPHERE]
+    assert em == pytest.approx([300 / (4 * np.pi ** 2 * rr * rr) for rr in (1.0, 0.5, 0.05)], rel=1e-6)   # parser.rs:567-575
+    s = host.LoadedScene(SCENES["semesterbild"])
+    assert s.c.n_triangles == 4748 and s.c.meshes[0].node_count == 3351 and s.c.meshes[0].max_depth == 11
+    t = host.LoadedScene(SCENES["teapot"], skip_unknown_primitives=True)
+    assert [t.c.meshes[i].triangle_count for i in range(2)] == [19369, 11968]            # WO3 3-index stride bug kept (App. B-2)
+    assert t.c.materials[1].kind == abi.MAT_LAMBERT_CHECKER and t.c.materials[1].p0 == pytest.approx(1 / 20)
+
+
+def test_unknown_primitive_is_a_hard_error_like_serde(native, abi):
+    host, _ = native
+    with pytest.raises(RuntimeError, match="unknown variant `infinite_sphere`"):
+        host.LoadedScene(SCENES["teapot"])
+
+
+def test_overrides_and_defaults(native, tmp_path, abi):
+    host, _ = native
+    a = host.LoadedScene(SCENES["cornell"], width=400, height=300, spp=16, max_depth=4)
+    assert (a.settings.width, a.settings.height, a.settings.samples_per_pixel, a.settings.max_depth) == (400, 300, 16, 4)
+    assert a.camera.half_width == pytest.approx(a.camera.half_height * 400 / 300, rel=1e-6)   # aspect follows W/H (parser.rs:294-297)
+    p = tmp_path / "min.json"
+    p.write_text(json.dumps({"camera": {"transform": {"position": [0, 0, 5], "look_at": {"x": 0, "y": 0, "z": 0}, "up": [0, 1, 0]}, "fov": 40},
+                             "primitives": [{"type": "sphere", "transform": {}, "bsdf": "nope"},
+                                            {"type": "plane", "point": [0, -1, 0], "normal": [0, 2, 0], "material": {"Metal": {"albedo": [0.8, 0.8, 0.8], "fuzz": 3.0}}}],
+                             "bsdfs": [{"name": "c", "type": "conductor"}]}))
+    m = host.LoadedScene(str(p))
+    assert (m.settings.width, m.settings.height, m.settings.samples_per_pixel, m.settings.max_depth) == (800, 600, 16, 10)   # parser.rs:255-258
+    assert m.c.n_materials == 2                         # "conductor" skipped; magenta fallback + inline metal
+    assert m.c.materials[0].kind == abi.MAT_LAMBERT_SOLID and list(m.c.materials[0].albedo) == [1.0, 0.0, 1.0]
+    assert m.c.materials[1].kind == abi.MAT_METAL and m.c.materials[1].p0 == 1.0            # fuzz clamped (material.rs:79-84)
+    assert list(m.c.primitives[1].data[3:6]) == [0.0, 1.0, 0.0]                              # Plane::new normalises
+    from oracle import scene_loader
+    o = scene_loader.load_scene(str(p))
+    assert np.array_equal(_bytes(m.c.primitives, 2, abi.Primitive), _bytes(o.c.primitives, 2, abi.Primitive))
+    assert np.array_equal(_bytes(m.c.materials, 2, abi.Material), _bytes(o.c.materials, 2, abi.Material))
+
+
+def test_png_writer_roundtrip(native, tmp_path):
+    host, _ = native
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 1 << 24, size=(7, 13), dtype=np.uint32)
+    path = str(tmp_path / "x.png")
+    host.write_png(path, img, 13, 7)
+    got = np.array(Image.open(path).convert("RGB")).astype(np.uint32)
+    assert np.array_equal((got[..., 0] << 16) | (got[..., 1] << 8) | got[..., 2], img)

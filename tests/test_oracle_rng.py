@@ -1,0 +1,61 @@
+"""Known-answer tests that pin the oracle's generators.
+
+ChaCha12 / seed_from_u64 vectors: SURVEY.md Appendix A -- captured from the survey's RNG whose renders
+reproduced the reference's committed docs/semesterbild.png pixel-for-pixel along row prefixes
+(rand 0.9.1 StdRng; the crate source is not in the container).
+Philox4x32-10 vectors: the Random123 distribution's kat_vectors (Salmon et al., SC'11).
+"""
+import numpy as np
+
+APPENDIX_A = {  # seed: (key words, u32[0..3], u32[16..17], u32[62..65], u32[128])
+    0: ("f973f2ec 45cdb581 7346f087 ad6cad06 e3a3d0d0 67e71733 72ea9bf2 fe7d8ad7", "cd2c6f7f bb2a3fb2 8e27697b c6017c94",
+        "9e0d7fac bfd4a4ae", "6fdc7e07 fa202be2 4c0bcc72 eadd98ee", "ddf70276"),
+    1: ("721dd8ea 4e10265d f83b9c89 2e78ce42 da03d3ba c2d29799 ac560212 1bfb6673", "d3301861 f9681a64 cc0d694a b0f4d125",
+        "1cb3b3a6 85353f1c", "0c3f0b5d 3c25aa00 06cc05a3 f4c4c9f5", "a4dbf589"),
+    299: ("eb787412 a1638c04 529643fc 74604ba3 745d1654 6612cb9a deb30e32 6ba274c4", "65b495d1 ee8afbbf e8a99d05 bbbd3a26",
+          "85f9f693 d52ae773", "6b3e0917 d4b27f44 1977fc1c 9e9b78c2", "c3391bb3"),
+    599: ("c8938b8a 61441041 9e0f226f 5285f794 c0d29729 6f86fea0 db5aedbc 633445a1", "def4f7e3 60c45fca 7d58f486 a8b56c58",
+          "4047391a 348b2f0e", "cdceb4bb 42bafa41 f70db215 1da04a59", "58850501"),
+}
+
+
+def _hex(s):
+    return [int(w, 16) for w in s.split()]
+
+
+def test_chacha12_seed_from_u64_and_stream(oracle_mod):
+    for seed, (key, w0, w16, w62, w128) in APPENDIX_A.items():
+        assert oracle_mod.chacha_key(seed).tolist() == _hex(key)
+        w = oracle_mod.chacha_words(seed, 129).tolist()
+        assert w[0:4] == _hex(w0)
+        assert w[16:18] == _hex(w16)          # second block of the first 4-block refill
+        assert w[62:66] == _hex(w62)          # across the refill boundary (block counter 4)
+        assert [w[128]] == _hex(w128)         # third refill
+
+
+def test_float_conversions(oracle_mod):
+    L = oracle_mod.lib()
+    w = oracle_mod.chacha_words(0, 7)
+    f01 = [np.float32(L.oracle_u32_to_f01(int(v))).view(np.uint32).item() for v in w[:4]]
+    assert f01 == [0x3f4d2c6f, 0x3f3b2a3f, 0x3f0e2769, 0x3f46017c]
+    assert w[4:7].tolist() == [0xcf310a16, 0x069dc102, 0xabe5f6d0]
+    r11 = [np.float32(L.oracle_u32_to_range11(int(v))).view(np.uint32).item() for v in w[4:7]]
+    assert r11 == [0x3f1e6214, 0xbf72c480, 0x3eaf97d8]
+    # range: [0,1) and [-1,1), 24 / 23 bits
+    assert L.oracle_u32_to_f01(0xFFFFFFFF) < 1.0 and L.oracle_u32_to_f01(0) == 0.0
+    assert -1.0 <= L.oracle_u32_to_range11(0) and L.oracle_u32_to_range11(0xFFFFFFFF) < 1.0
+
+
+def test_philox4x32_10_kat(oracle_mod):
+    assert oracle_mod.philox(0, 0, 0, 0, 0, 0).tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xFFFFFFFF
+    assert oracle_mod.philox(f, f, f, f, f, f).tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle_mod.philox(0xa4093822, 0x299f31d0, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344).tolist() == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_ctr_stream_first_sample_of_a_row_is_keyed_by_row(oracle_mod, abi):
+    """Two rows never share a key and a seed offset of k equals shifting the row by k."""
+    a = oracle_mod.philox(5, 0, 1, 2, 0, 0).tolist()
+    b = oracle_mod.philox(6, 0, 1, 2, 0, 0).tolist()
+    assert a != b
