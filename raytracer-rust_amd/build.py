@@ -22,8 +22,10 @@ CLI = os.path.join(OUT, "rt_render")
 
 # -ffp-contract=off: no FMA contraction -- the reference (rustc) never fuses a*b+c, and parity with the
 # CPU oracle is bit-level.  Correctly rounded f32 divide/sqrt are HIP's default; stated explicitly.
+# -fno-slp-vectorize: hipcc's SLP pass packs adjacent f32 ops into v_pk_mul/add_f32, which issue slower than
+# the two scalar ops they replace on gfx950 (measured: -6 % kernel time on cornell, identical results).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-Wall",
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-command-line-argument"]
 CXX_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-pthread"]
 
@@ -64,6 +66,18 @@ def build_device(force=False, extra_flags=(), verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     return DEVICE_SO
+
+
+def build_device_variant(name, defines=(), force=False, verbose=False, flags=()):
+    """Diagnostic / A-B builds (e.g. cycle stamps) into their own library; never loaded by the product path."""
+    os.makedirs(OUT, exist_ok=True)
+    so = os.path.join(OUT, f"libmi355rt_{name}.so")
+    if force or _stale(so, DEVICE_DEPS):
+        cmd = [hipcc_path(), *HIPCC_FLAGS, *flags, *[f"-D{d}" for d in defines], "-o", so, *DEVICE_SRCS]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return so
 
 
 def build_host(force=False, verbose=False):

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,6 +51,15 @@ int check_settings(const mi355rt_settings* st) {
     return MI355RT_OK;
 }
 
+// q = n / d for every n < 2^31 as umulhi(n, mul) >> shift (mul == 0 encodes d == 1).  s = ceil(log2 d),
+// mul = ceil(2^(31+s) / d) < 2^32, shift = s - 1.
+void magic_div(uint32_t d, uint32_t& mul, uint32_t& shift) {
+    if (d <= 1) { mul = 0; shift = 0; return; }
+    uint32_t s = 0; while ((1ull << s) < d) ++s;
+    const unsigned __int128 num = (unsigned __int128)1 << (31 + s);
+    mul = (uint32_t)((num + d - 1) / d); shift = s - 1;
+}
+
 template <class T> struct DevBuf {
     T* p = nullptr; size_t n = 0;
     int ensure(size_t count) {
@@ -68,7 +78,9 @@ template <class T> struct DevBuf {
 struct mi355rt_context {
     int device = 0;
     int cu_count = 0;
-    int blocks_per_cu = 0, vgprs = 0, sgprs = 0;
+    int blocks_per_cu[3] = {0, 0, 0}, vgprs[3] = {0, 0, 0}, sgprs = 0;
+    uint32_t variant = KERNEL_LOCKSTEP;  // chosen per scene in set_scene
+    uint32_t trav_min = 24;              // measured optimum 24-32 on semesterbild / teapot (tools/ab_kernel.py)
     bool have_scene = false;
     mi355rt_settings settings{};
     DevCamera cam{};
@@ -193,6 +205,15 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     if (!tris.empty()) HIP_TRY(hipMemcpy(ctx->tris.p, tris.data(), tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
     ctx->n_prims = sc->n_primitives; ctx->n_mats = sc->n_materials;
     std::memcpy(ctx->miss, sc->miss_color, 12);
+    bool has_mesh = false;
+    for (const auto& pr : prims) has_mesh = has_mesh || pr.kind == MI355RT_PRIM_MESH;
+    ctx->variant = has_mesh ? KERNEL_STATE_MACHINE : KERNEL_LOCKSTEP;
+    if (const char* e = std::getenv("MI355RT_KERNEL")) {            // A/B override (tools/): 0 lockstep, 1 lockstep+mesh, 2 state machine
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 2 && (v != KERNEL_LOCKSTEP || !has_mesh)) ctx->variant = (uint32_t)v;
+    }
+    ctx->trav_min = 24;
+    if (const char* e = std::getenv("MI355RT_TRAV_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->trav_min = (uint32_t)v; }
     return MI355RT_OK;
 }
 
@@ -223,9 +244,11 @@ int mi355rt_context_create(int hip_device, mi355rt_context** out_ctx) {
     if (!ctx) return fail(MI355RT_ERR_OOM, "host allocation failed");
     ctx->device = hip_device;
     ctx->cu_count = prop.multiProcessorCount;
-    if (query_render_ctr_occupancy(&ctx->blocks_per_cu, &ctx->vgprs, &ctx->sgprs) != 0 || ctx->blocks_per_cu <= 0) {
-        delete ctx;
-        return fail(MI355RT_ERR_HIP, std::string("kernel image not usable on this device (") + prop.gcnArchName + "); built for gfx950");
+    for (uint32_t v = 0; v < 3; ++v) {
+        if (query_render_ctr_occupancy(v, &ctx->blocks_per_cu[v], &ctx->vgprs[v], &ctx->sgprs) != 0 || ctx->blocks_per_cu[v] <= 0) {
+            delete ctx;
+            return fail(MI355RT_ERR_HIP, std::string("kernel image not usable on this device (") + prop.gcnArchName + "); built for gfx950");
+        }
     }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return fail(MI355RT_ERR_HIP, "hipEventCreate"); }
     *out_ctx = ctx;
@@ -274,7 +297,7 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
     const uint32_t rng_mode = opt ? opt->rng_mode : (uint32_t)MI355RT_RNG_CTR;
     const uint64_t seed = opt ? opt->seed : 0;
     const uint32_t n_rows = (uint32_t)ctx->rows_host.size();
-    if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
+    if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs[ctx->variant]; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
     if (n_rows == 0) return MI355RT_OK;
 
     if (!same_rows) {
@@ -282,8 +305,8 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         HIP_TRY(hipMemcpyAsync(ctx->rows.p, ctx->rows_host.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         ctx->rows_valid = true;
     }
-    if ((rc = ctx->stats.ensure(2))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, 2 * sizeof(unsigned long long), stream));
+    if ((rc = ctx->stats.ensure(16))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, 16 * sizeof(unsigned long long), stream));
 
     double render_ms = 0, resolve_ms = 0, total_ms = 0;
     uint32_t n_bands = 0, grid_blocks = 0, block_threads = 0;
@@ -326,10 +349,12 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         std::memcpy(p.miss, ctx->miss, 12); p.cam = ctx->cam;
         p.width = st.width; p.height = st.height; p.spp = st.samples_per_pixel; p.max_depth = st.max_depth;
         p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+        magic_div(st.samples_per_pixel, p.spp_mul, p.spp_shift); magic_div(st.width, p.width_mul, p.width_shift);
+        p.trav_min = ctx->trav_min;
         ResolveParams r{};
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
         r.spp = st.samples_per_pixel; r.inv_spp = 1.0f / (float)st.samples_per_pixel;     // renderer.rs:85
-        const uint32_t resident = (uint32_t)(ctx->cu_count * ctx->blocks_per_cu);
+        const uint32_t resident = (uint32_t)(ctx->cu_count * ctx->blocks_per_cu[ctx->variant]);
         block_threads = BLOCK_THREADS;
         std::vector<float> band_ms;
         for (uint32_t b = 0; b < n_bands; ++b) {
@@ -346,7 +371,7 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
             if (ctx->timing && !stats) { pe0 = ctx->pool_get(); pe1 = ctx->pool_get(); pe2 = ctx->pool_get(); if (!pe0 || !pe1 || !pe2) return fail(MI355RT_ERR_HIP, "event pool"); }
             if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], stream));
             if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
-            if (launch_render_ctr(p, grid, stream) != 0) return fail(MI355RT_ERR_HIP, "k_render_ctr launch failed");
+            if (launch_render_ctr(p, ctx->variant, grid, stream) != 0) return fail(MI355RT_ERR_HIP, "k_render_ctr launch failed");
             if (stats) HIP_TRY(hipEventRecord(ctx->ev[1], stream));
             if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
             if (launch_resolve(r, stream) != 0) return fail(MI355RT_ERR_HIP, "k_resolve launch failed");
@@ -369,6 +394,14 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         stats->samples = h[0]; stats->rays = h[1];
         stats->bands = n_bands; stats->grid_blocks = grid_blocks; stats->block_threads = block_threads;
     }
+    return MI355RT_OK;
+}
+
+// Diagnostic hook (not part of the public header): the 16 raw device counters of the last render.
+int mi355rt_debug_read_counters(mi355rt_context* ctx, unsigned long long* out16) {
+    if (!ctx || !out16 || !ctx->stats.p) return fail(MI355RT_ERR_INVALID, "no counters");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(out16, ctx->stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MI355RT_OK;
 }
 

@@ -61,6 +61,15 @@ struct RenderParams {
     uint32_t band_samples;       // band pixels * spp  (< 2^31)
     uint32_t n_batches;
     uint32_t seed_lo, seed_hi;
+    uint32_t spp_mul, spp_shift, width_mul, width_shift;   // magic pairs for n / spp and n / width (n < 2^31)
+    uint32_t trav_min;           // state-machine kernel: run BVH rounds while at least this many lanes are walking
+};
+
+// Which counter-mode kernel serves a scene
+enum : uint32_t {
+    KERNEL_LOCKSTEP = 0,         // no mesh at the top level: every lane traces a whole ray per iteration
+    KERNEL_LOCKSTEP_MESH = 1,    // same loop with the per-lane BVH walk inlined (A/B reference for the state machine)
+    KERNEL_STATE_MACHINE = 2     // wave-voted TRAV / TOP / SHADE blocks (scenes with meshes)
 };
 
 struct ResolveParams {
@@ -85,9 +94,9 @@ struct RefParams {               // MI355RT_RNG_REF: one lane per selected row
 };
 
 // launchers (rt_kernels.hip); `stream` is a hipStream_t
-int launch_render_ctr(const RenderParams& p, uint32_t grid_blocks, void* stream);
+int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blocks, void* stream);
 int launch_resolve(const ResolveParams& p, void* stream);
 int launch_render_ref(const RefParams& p, void* stream);
-int query_render_ctr_occupancy(int* blocks_per_cu, int* vgprs, int* sgprs);
+int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs);
 
 }  // namespace mi355rt

@@ -38,6 +38,24 @@ constexpr float PI_F = 3.14159265358979323846f;   // std::f32::consts::PI
 
 typedef const __attribute__((address_space(4))) DevPrim* cprim_t;   // wave-uniform reads -> s_load
 
+// Diagnostic-only cycle stamps (build with -DMI355RT_STAMPS into a separate library; the product build
+// compiles Prof to nothing).  Shares of wave time per section, summed over waves, land in stats[2..].
+#ifdef MI355RT_STAMPS
+struct Prof {
+    unsigned long long acc[6]; unsigned long long last;
+    DI void begin() { for (int i = 0; i < 6; ++i) acc[i] = 0; last = now(); }
+    DI static unsigned long long now() {
+        unsigned long long t; __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0); return t;
+    }
+    DI void mark(int i) { unsigned long long t = now(); acc[i] += t - last; last = t; }
+};
+#else
+struct Prof { DI void begin() {} DI void mark(int) {} };
+#endif
+
+
 // ---------------------------------------------------------------------------------------------------
 // vec3.rs
 // ---------------------------------------------------------------------------------------------------
@@ -110,10 +128,14 @@ DI void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32
 struct RngCtr {
     uint32_t k0, k1, x, s, ray;
     uint32_t b0[4];
-    DI void start(uint32_t k0_, uint32_t k1_, uint32_t x_, uint32_t s_) { k0 = k0_; k1 = k1_; x = x_; s = s_; ray = 0; philox4x32_10(k0, k1, x, s, 0u, 0u, b0); }
+    // One Philox call per loop iteration serves BOTH kinds of lanes: a freshly dealt path reads its camera
+    // jitter from (ray 0, block 0); a continuing path reads its scatter draws from (ray r+1, block 0).
+    DI void start(uint32_t k0_, uint32_t k1_, uint32_t x_, uint32_t s_) { k0 = k0_; k1 = k1_; x = x_; s = s_; ray = 0; }
+    DI void next_event() { ++ray; }
+    DI void load_block0() { philox4x32_10(k0, k1, x, s, ray, 0u, b0); }
     DI float jitter_u() { return u32_to_f01(b0[0]); }
     DI float jitter_v() { return u32_to_f01(b0[1]); }
-    DI void begin_scatter() { ++ray; philox4x32_10(k0, k1, x, s, ray, 0u, b0); }
+    DI void begin_scatter() {}
     DI float uniform01_0() { return u32_to_f01(b0[0]); }
     DI float uniform01_1() { return u32_to_f01(b0[1]); }
     DI f3 cube_point(uint32_t j) {
@@ -290,65 +312,91 @@ DI bool hit_cube(cprim_t pr, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h)
 }
 
 // mesh/mesh_object.rs:263-329 + acceleration/bvh.rs:78-170 + acceleration/aabb.rs:27-45.
-// Threaded pre-order walk; `best_t` plays the role of the recursion's shrinking t_max.
-DI bool hit_mesh(cprim_t pr, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro_w, f3 rd_w,
-                 float t_min, float t_max, Hit& h) {
-    f3 ro = xform_w2o_point(pr, ro_w);
+// Threaded pre-order walk; `best_t` plays the role of the recursion's shrinking t_max.  The walk is split
+// into setup / inner-node step / leaf / finalize so that the state-machine kernel can interleave the
+// traversals of different lanes; hit_mesh() composes them into the plain per-lane loop.
+struct MeshTrav {
+    f3 ro, rd;                 // object-space ray (direction normalised twice, mesh_object.rs:289)
+    float ix, iy, iz;          // 1/d, aabb.rs:29 (same value at every node)
+    float len_raw;             // |w2o * d_world| for the (sic) t_world formula
+    uint32_t node, end;        // pre-order cursor / one past the mesh's last node
+    float best_t; uint32_t best_tri;
+    uint32_t leaf_a, leaf_b;   // pending leaf (first triangle, count); leaf_b == 0: none
+};
+DI void mesh_setup(cprim_t pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {
+    m.ro = xform_w2o_point(pr, ro_w);
     f3 rd_raw = xform_w2o_dir(pr, rd_w);
-    f3 rd = normalized(normalized(rd_raw));              // Ray::new(o, d.normalized()), mesh_object.rs:289
-    const float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;   // aabb.rs:29 (same value at every node)
-    uint32_t node = pr->node_begin;
-    const uint32_t end = pr->node_end;
-    float best_t = t_max; uint32_t best_tri = 0xFFFFFFFFu;
-    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(nodes);
-    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(tris);
-    while (node < end) {
-        const float4 q0 = n4[2 * (size_t)node], q1 = n4[2 * (size_t)node + 1];
-        const uint32_t a = __float_as_uint(q0.w), b = __float_as_uint(q1.w);
-        float tmin = t_min, tmax = best_t;
-        bool ok = true;
-        {   float t0 = (q0.x - ro.x) * ix, t1 = (q1.x - ro.x) * ix; if (ix < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-            tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
-        {   float t0 = (q0.y - ro.y) * iy, t1 = (q1.y - ro.y) * iy; if (iy < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-            tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
-        {   float t0 = (q0.z - ro.z) * iz, t1 = (q1.z - ro.z) * iz; if (iz < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-            tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
-        if (!ok) { node = b ? node + 1 : a; continue; }   // skip subtree (a leaf's successor is node+1)
-        if (b == 0) { node = node + 1; continue; }        // inner: left child first
-        for (uint32_t k = 0; k < b; ++k) {                // leaf: Moeller-Trumbore, bvh.rs:91-138
-            const size_t ti = 3 * (size_t)(a + k);
-            const float4 r0 = t4[ti], r1 = t4[ti + 1], r2 = t4[ti + 2];
-            const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
-            f3 hh = cross(rd, e2);
-            float aa = dot(e1, hh);
-            if (fabsf(aa) < EPS) continue;
-            float f = 1.0f / aa;
-            f3 s = ro - v0;
-            float u = f * dot(s, hh);
-            if (!(u >= 0.0f && u <= 1.0f)) continue;
-            f3 q = cross(s, e1);
-            float v = f * dot(rd, q);
-            if (v < 0.0f || u + v > 1.0f) continue;
-            float t = f * dot(e2, q);
-            if (t > t_min && t < best_t) { best_t = t; best_tri = a + k; }
-        }
-        node = node + 1;
+    m.len_raw = len(rd_raw);
+    m.rd = normalized(normalized(rd_raw));
+    m.ix = 1.0f / m.rd.x; m.iy = 1.0f / m.rd.y; m.iz = 1.0f / m.rd.z;
+    m.node = pr->node_begin; m.end = pr->node_end;
+    m.best_t = t_max; m.best_tri = 0xFFFFFFFFu; m.leaf_b = 0; m.leaf_a = 0;
+}
+// Visit m.node (box test, aabb.rs:27-45).  Afterwards either m.node moved on, or a leaf is pending (m.leaf_b > 0).
+DI void mesh_step(const float4* __restrict__ n4, float t_min, MeshTrav& m) {
+    const float4 q0 = n4[2 * (size_t)m.node], q1 = n4[2 * (size_t)m.node + 1];
+    const uint32_t a = __float_as_uint(q0.w), b = __float_as_uint(q1.w);
+    float tmin = t_min, tmax = m.best_t;
+    bool ok = true;
+    {   float t0 = (q0.x - m.ro.x) * m.ix, t1 = (q1.x - m.ro.x) * m.ix; if (m.ix < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
+    {   float t0 = (q0.y - m.ro.y) * m.iy, t1 = (q1.y - m.ro.y) * m.iy; if (m.iy < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
+    {   float t0 = (q0.z - m.ro.z) * m.iz, t1 = (q1.z - m.ro.z) * m.iz; if (m.iz < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
+    if (!ok) { m.node = b ? m.node + 1 : a; }             // skip subtree (a leaf's successor is node+1)
+    else if (b == 0) { m.node = m.node + 1; }             // inner: left child first
+    else { m.leaf_a = a; m.leaf_b = b; }                  // leaf whose box was hit: triangles pending
+}
+// Moeller-Trumbore over the pending leaf, bvh.rs:91-138
+DI void mesh_leaf(const float4* __restrict__ t4, float t_min, MeshTrav& m) {
+    for (uint32_t k = 0; k < m.leaf_b; ++k) {
+        const size_t ti = 3 * (size_t)(m.leaf_a + k);
+        const float4 r0 = t4[ti], r1 = t4[ti + 1], r2 = t4[ti + 2];
+        const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+        f3 hh = cross(m.rd, e2);
+        float aa = dot(e1, hh);
+        if (fabsf(aa) < EPS) continue;
+        float f = 1.0f / aa;
+        f3 s = m.ro - v0;
+        float u = f * dot(s, hh);
+        if (!(u >= 0.0f && u <= 1.0f)) continue;
+        f3 q = cross(s, e1);
+        float v = f * dot(m.rd, q);
+        if (v < 0.0f || u + v > 1.0f) continue;
+        float t = f * dot(e2, q);
+        if (t > t_min && t < m.best_t) { m.best_t = t; m.best_tri = m.leaf_a + k; }
     }
-    if (best_tri == 0xFFFFFFFFu) return false;
-    const float4 r2 = t4[3 * (size_t)best_tri + 2];
+    m.leaf_b = 0; m.node = m.node + 1;
+}
+DI bool mesh_finalize(cprim_t pr, const float4* __restrict__ t4, const MeshTrav& m, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h) {
+    if (m.best_tri == 0xFFFFFFFFu) return false;
+    const float4 r2 = t4[3 * (size_t)m.best_tri + 2];
     f3 tn = mk(r2.y, r2.z, r2.w);
-    f3 pos_obj = ro + rd * best_t;
-    f3 n_obj = (dot(rd, tn) < 0.0f) ? tn : -tn;                         // bvh.rs:118-124
+    f3 pos_obj = m.ro + m.rd * m.best_t;
+    f3 n_obj = (dot(m.rd, tn) < 0.0f) ? tn : -tn;                       // bvh.rs:118-124
     f3 pw = xform_o2w_point(pr, pos_obj);
     f3 nw = normalized(xform_normal(pr, n_obj));
-    float t_world = best_t * len(rd_raw) / len(rd_w);                   // (sic) mesh_object.rs:312-314
+    float t_world = m.best_t * m.len_raw / len(rd_w);                   // (sic) mesh_object.rs:312-314
     if (t_world < t_min || t_world > t_max) return false;
     h.t = t_world; h.p = pw;
     set_face(h, rd_w, nw, pr->material);
     return true;
 }
+DI bool hit_mesh(cprim_t pr, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro_w, f3 rd_w,
+                 float t_min, float t_max, Hit& h) {
+    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(nodes);
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(tris);
+    MeshTrav m; mesh_setup(pr, ro_w, rd_w, t_max, m);
+    while (m.node < m.end) {
+        mesh_step(n4, t_min, m);
+        if (m.leaf_b) mesh_leaf(t4, t_min, m);
+    }
+    return mesh_finalize(pr, t4, m, ro_w, rd_w, t_min, t_max, h);
+}
 
 // hittable.rs:45-58 -- HittableList::hit with t_min = EPSILON, t_max = INFINITY (renderer.rs:24)
+template <bool HAS_MESH>
 DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris,
                   f3 ro, f3 rd, Hit& best) {
     float closest = __builtin_inff();
@@ -361,7 +409,7 @@ DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
             case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ro, rd, EPS, closest, h); break;
             case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ro, rd, EPS, closest, h); break;
             case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, ro, rd, EPS, closest, h); break;
-            default:                  hit = hit_mesh(pr, nodes, tris, ro, rd, EPS, closest, h); break;
+            default:                  if (HAS_MESH) hit = hit_mesh(pr, nodes, tris, ro, rd, EPS, closest, h); break;
         }
         if (hit) { closest = h.t; best = h; any = true; }
     }
@@ -414,9 +462,8 @@ DI float beckmann_lambda(float a, float x) {                                    
 // Result of one surface interaction (renderer.rs:26-36): either the path goes on (scattered ray +
 // attenuation) or it ends with `emitted` (scatter -> None).
 template <class Rng>
-DI bool surface_scatter(const DevMat* __restrict__ mats, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted) {
+DI bool surface_scatter(const DevMat* __restrict__ mats, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted, Prof& prof) {
     const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
-    const float4 q0 = m4[0];
     const uint32_t kind = __float_as_uint(q0.x);
     const f3 albedo = mk(q0.y, q0.z, q0.w);
     const bool front_face = (h.mat_ff >> 31) != 0;
@@ -521,6 +568,7 @@ DI bool surface_scatter(const DevMat* __restrict__ mats, const Hit& h, f3 rd_in,
         new_o = h.p + n * EPS;
         new_d = normalized(normalized(l));
     }
+    prof.mark(2);
     if (diffuse) {                                                                 // material.rs:54-62
         f3 p; uint32_t j = 0;
         do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));              // vec3.rs:54-61
@@ -529,6 +577,7 @@ DI bool surface_scatter(const DevMat* __restrict__ mats, const Hit& h, f3 rd_in,
         new_o = h.p + h.n * EPS;
         new_d = normalized(normalized(dir));                                       // .normalized() then Ray::new
     }
+    prof.mark(3);
     return true;
 }
 
@@ -551,91 +600,255 @@ DI uint32_t wave_sum(uint32_t v) {
 }
 
 // ===================================================================================================
-// k_render_ctr -- persistent, path-regenerating wave64 path tracer
+// Shared pieces of the two counter-mode kernels
 // ===================================================================================================
-__global__ void __launch_bounds__(BLOCK_THREADS) k_render_ctr(const RenderParams P) {
+// n / d for n < 2^31 with a host-computed magic pair (mul == 0 means d == 1): q = umulhi(n, mul) >> shift.
+DI uint32_t fastdiv(uint32_t n, uint32_t mul, uint32_t shift) { return mul ? (__umulhi(n, mul) >> shift) : n; }
+
+// Wave-uniform cursor over the band's sample indices.  A wave claims BATCH_SAMPLES consecutive indices
+// with one global atomic and deals them to idle lanes with ballot + mbcnt.
+struct WorkCursor {
+    uint32_t next = 0, end = 0; bool no_more = false;
+    DI bool exhausted() const { return no_more && next == end; }
+    // Lanes with want == true get a sample index (returns true and sets sidx); others / surplus stay idle.
+    DI bool deal(const RenderParams& P, bool want, uint32_t lane, uint32_t& sidx) {
+        const uint64_t idle = __ballot(want);
+        if (idle == 0ull) return false;
+        if (next == end && !no_more) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(P.batch_counter, 1u);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= P.n_batches) no_more = true;
+            else { next = b * BATCH_SAMPLES; end = min(next + BATCH_SAMPLES, P.band_samples); }
+        }
+        const uint32_t take = min((uint32_t)__popcll(idle), end - next);
+        bool got = false;
+        if (take != 0u) {
+            const uint32_t rank = mbcnt64(idle);
+            if (want && rank < take) { sidx = next + rank; got = true; }
+            next += take;
+        }
+        return got;
+    }
+};
+
+// Decode a band-local sample index into (x, y, s) and key the path's RNG (renderer.rs:91-97).
+DI void start_path(const RenderParams& P, uint32_t sidx, RngCtr& rng, uint32_t& px, uint32_t& py) {
+    const uint32_t pix_local = fastdiv(sidx, P.spp_mul, P.spp_shift);
+    const uint32_t s = sidx - pix_local * P.spp;
+    const uint32_t pix = P.band_pixel0 + pix_local;
+    const uint32_t jrow = fastdiv(pix, P.width_mul, P.width_shift);
+    px = pix - jrow * P.width;
+    py = P.rows[jrow];
+    const uint64_t ykey = (uint64_t)py + (((uint64_t)P.seed_hi << 32) | (uint64_t)P.seed_lo);
+    rng.start((uint32_t)ykey, (uint32_t)(ykey >> 32), px, s);
+}
+
+// Per-lane path state shared by both kernels.
+struct PathState {
+    f3 ro, rd, thr;
+    uint32_t sidx, ray_index;
+    uint32_t px, py;               // only meaningful while `fresh`
+    RngCtr rng;
+};
+
+// The shading half of one trace_ray level (renderer.rs:26-36) plus path regeneration, for every lane of the
+// wave at once.  On entry `live` lanes carry a finished intersection (`hit`, `h`); on exit `live` lanes carry
+// the next ray to trace.  Order: finish paths that end without scattering (miss / emitter / null) ->
+// deal fresh samples to idle lanes -> ONE Philox call for all lanes -> camera ray (fresh) or BSDF (continuing).
+// Must be called by the whole wave in uniform control flow (it ballots): lanes that are busy elsewhere
+// pass live = false and can_take = false and are left untouched.
+// Returns false when no lane is live afterwards and no work is left to deal.
+DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
+                             PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
+    float4* __restrict__ radiance = reinterpret_cast<float4*>(P.radiance);
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        f3 term = mk(0.f, 0.f, 0.f); bool fin = false;
+        if (!hit) { term = mk(P.miss[0], P.miss[1], P.miss[2]); fin = true; }            // renderer.rs:61
+        else {
+            q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
+            const uint32_t kind = __float_as_uint(q0.x);
+            if (kind == MI355RT_MAT_EMISSIVE) { term = mk(q0.y, q0.z, q0.w); fin = true; }   // scatter -> None, emitted = colour
+            else if (kind == MI355RT_MAT_NULL) fin = true;
+        }
+        if (fin) { const f3 L = ps.thr * term; radiance[ps.sidx] = make_float4(L.x, L.y, L.z, 0.0f); live = false; }
+    }
+    prof.mark(2);
+    bool fresh = false;
+    if (wc.deal(P, can_take && !live, lane, ps.sidx)) { start_path(P, ps.sidx, ps.rng, ps.px, ps.py); fresh = true; live = true; ++n_paths; }
+    if (__ballot(live) == 0ull) return !wc.exhausted();
+    if (live) {
+        if (!fresh) ps.rng.next_event();
+        ps.rng.load_block0();
+        if (fresh) {
+            const float u = ((float)ps.px + ps.rng.jitter_u()) / (float)P.width;         // renderer.rs:96
+            const float v = ((float)ps.py + ps.rng.jitter_v()) / (float)P.height;        // renderer.rs:97
+            camera_ray(P.cam, u, v, ps.ro, ps.rd);                                       // renderer.rs:99
+            ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
+            if (P.max_depth == 0u) { radiance[ps.sidx] = make_float4(0.f, 0.f, 0.f, 0.f); live = false; }   // depth == 0 -> BLACK
+        } else {
+            f3 no, nd, atten, emitted;
+            if (surface_scatter(P.mats, q0, h, ps.rd, ps.rng, no, nd, atten, emitted, prof)) {
+                ps.thr = ps.thr * atten; ps.ro = no; ps.rd = nd; ++ps.ray_index;
+                if (ps.ray_index == P.max_depth) {                                       // next level has depth == 0 (renderer.rs:20-22)
+                    const f3 L = ps.thr * mk(0.f, 0.f, 0.f);
+                    radiance[ps.sidx] = make_float4(L.x, L.y, L.z, 0.0f); live = false;
+                }
+            } else {                                                                     // absorbed: scatter -> None (renderer.rs:35)
+                const f3 L = ps.thr * emitted;
+                radiance[ps.sidx] = make_float4(L.x, L.y, L.z, 0.0f); live = false;
+            }
+        }
+        if (live) ++n_rays;
+    }
+    prof.mark(3);
+    return true;
+}
+
+// Register budget per kernel, as waves per SIMD (A/B: tools/ab.py).  The lockstep kernel is VALU-issue bound
+// and gains from 6 waves/SIMD even with a few spills; the state-machine kernel keeps its hot BVH state in
+// registers and loses when capped.
+#ifndef MI355RT_OCC_LOCKSTEP
+#define MI355RT_OCC_LOCKSTEP 6
+#endif
+#if MI355RT_OCC_LOCKSTEP > 0
+#define MI355RT_OCC_LS __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_LOCKSTEP, MI355RT_OCC_LOCKSTEP)))
+#else
+#define MI355RT_OCC_LS
+#endif
+#ifndef MI355RT_OCC_SM
+#define MI355RT_OCC_SM 4
+#endif
+#if MI355RT_OCC_SM > 0
+#define MI355RT_OCC_SMK __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_SM, MI355RT_OCC_SM)))
+#else
+#define MI355RT_OCC_SMK
+#endif
+
+// ===================================================================================================
+// k_render_ctr<HAS_MESH> -- persistent, path-regenerating wave64 path tracer, lockstep form: every live lane
+// traces one full ray per loop iteration.  Used for scenes whose top level has no mesh (cornell, veach-mis):
+// all lanes walk the same primitive list, so the iteration is divergence-free up to the hit tests.
+// ===================================================================================================
+template <bool HAS_MESH>
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr(const RenderParams P) {
     cprim_t prims = (cprim_t)(P.prims);
     const uint32_t lane = threadIdx.x & 63u;
-
-    // wave-uniform work cursor: [b_next, b_end) are unclaimed sample indices of the wave's current batch
-    uint32_t b_next = 0, b_end = 0;
-    bool no_more = false;
-
-    // per-lane path state
-    bool active = false;
-    uint32_t sidx = 0;              // band-local sample index (where the radiance goes)
-    uint32_t ray_index = 0;         // rays already traced on this path
-    f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1), thr = mk(1, 1, 1);
-    RngCtr rng; rng.k0 = rng.k1 = rng.x = rng.s = rng.ray = 0; rng.b0[0] = rng.b0[1] = rng.b0[2] = rng.b0[3] = 0;
+    WorkCursor wc;
+    PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
+    ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
+    bool live = false;
     uint32_t n_paths = 0, n_rays = 0;
-    float4* __restrict__ radiance = reinterpret_cast<float4*>(P.radiance);
+    Prof prof; prof.begin();
+    for (;;) {
+        Hit h; bool hit = false;
+        h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
+        if (live) hit = hit_scene<HAS_MESH>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
+        prof.mark(1);
+        if (!shade_and_regenerate(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        prof.mark(4);
+    }
+#ifdef MI355RT_STAMPS
+    if (lane == 0 && P.stats) for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
+#endif
+    const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
+    if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }
+}
+
+// ===================================================================================================
+// k_render_ctr_sm -- the same path tracer as a wave-scheduled state machine, for scenes with meshes.
+// A per-lane BVH walk makes a lockstep wave run as long as its slowest ray (measured: 14 % VALU lane
+// utilisation on semesterbild).  Here every lane is in one of three states and each loop iteration the
+// wave VOTES (ballot + popcount) which block to run:
+//   TRAV   one "while-while" round of the threaded BVH walk (inner-node steps until every walking lane has a
+//          leaf pending or is done, then the leaf triangle tests) -- cheap, run while >= trav_min lanes walk;
+//   TOP    the top-level list from each lane's own cursor (records still come through scalar loads: the
+//          list index is wave-uniform, lanes join when it reaches their cursor); a mesh primitive either
+//          starts a walk (-> TRAV) or, when its walk is done, finalises the hit and moves on;
+//   SHADE  shade_and_regenerate() for lanes whose list is finished (and idle lanes).
+// Lanes that finish a walk early wait in TOP until enough of them have gathered, instead of idling inside
+// a divergent while loop.  Results are bit-identical to the lockstep kernel: every lane executes exactly the
+// same arithmetic in the same per-lane order.
+// ===================================================================================================
+enum : uint32_t { ST_IDLE = 0, ST_TOP = 1, ST_TRAV = 2, ST_SHADE = 3 };
+
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm(const RenderParams P) {
+    cprim_t prims = (cprim_t)(P.prims);
+    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
+    const uint32_t lane = threadIdx.x & 63u;
+    WorkCursor wc;
+    PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
+    ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
+    uint32_t state = ST_IDLE, cursor = 0;
+    bool walk_done = false;
+    float closest = __builtin_inff(); bool any_hit = false;
+    Hit best; best.t = 0.f; best.p = mk(0, 0, 0); best.n = mk(0, 0, 0); best.mat_ff = 0;
+    MeshTrav mt; mt.ro = mk(0, 0, 0); mt.rd = mk(0, 0, 1); mt.ix = mt.iy = mt.iz = 0.f; mt.len_raw = 0.f; mt.node = mt.end = 0; mt.best_t = 0.f;
+    mt.best_tri = 0xFFFFFFFFu; mt.leaf_a = mt.leaf_b = 0;
+    uint32_t n_paths = 0, n_rays = 0;
+    Prof prof; prof.begin();
+    const uint32_t trav_min = P.trav_min;
 
     for (;;) {
-        // ---- path regeneration: deal unclaimed samples to idle lanes (ballot + mbcnt compaction) ----
-        const uint64_t idle = __ballot(!active);
-        if (idle != 0ull) {
-            if (b_next == b_end && !no_more) {
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(P.batch_counter, 1u);
-                b = __builtin_amdgcn_readfirstlane(b);
-                if (b >= P.n_batches) { no_more = true; }
-                else { b_next = b * BATCH_SAMPLES; b_end = min(b_next + BATCH_SAMPLES, P.band_samples); }
-            }
-            const uint32_t avail = b_end - b_next;
-            const uint32_t take = min((uint32_t)__popcll(idle), avail);
-            if (take != 0u) {
-                const uint32_t rank = mbcnt64(idle);
-                if (!active && rank < take) {
-                    sidx = b_next + rank;
-                    const uint32_t pix_local = sidx / P.spp;
-                    const uint32_t s = sidx - pix_local * P.spp;
-                    const uint32_t pix = P.band_pixel0 + pix_local;
-                    const uint32_t jrow = pix / P.width;
-                    const uint32_t x = pix - jrow * P.width;
-                    const uint32_t y = P.rows[jrow];
-                    const uint64_t ykey = (uint64_t)y + (((uint64_t)P.seed_hi << 32) | (uint64_t)P.seed_lo);
-                    rng.start((uint32_t)ykey, (uint32_t)(ykey >> 32), x, s);
-                    const float u = ((float)x + rng.jitter_u()) / (float)P.width;    // renderer.rs:96
-                    const float v = ((float)y + rng.jitter_v()) / (float)P.height;   // renderer.rs:97
-                    camera_ray(P.cam, u, v, ro, rd);                                 // renderer.rs:99
-                    thr = mk(1.f, 1.f, 1.f);
-                    ray_index = 0;
-                    active = true;
-                    ++n_paths;
-                }
-                b_next += take;
-            }
-            if (__ballot(active) == 0ull) { if (no_more) break; else continue; }
-        }
+        const uint32_t nT = (uint32_t)__popcll(__ballot(state == ST_TRAV));
+        const uint32_t nP = (uint32_t)__popcll(__ballot(state == ST_TOP));
+        const uint32_t nS = (uint32_t)__popcll(__ballot(state == ST_SHADE));
+        const uint32_t nI = wc.exhausted() ? 0u : (uint32_t)__popcll(__ballot(state == ST_IDLE));
+        if (nT + nP + nS + nI == 0u) break;
 
-        // ---- one trace_ray level (renderer.rs:19-65) for every live lane ----
-        if (active) {
-            f3 term = mk(0.f, 0.f, 0.f);
-            bool done = false;
-            if (ray_index == P.max_depth) {                       // depth == 0 -> Color::BLACK (renderer.rs:20-22)
-                done = true;
-            } else {
-                ++n_rays;
-                Hit h;
-                if (!hit_scene(prims, P.n_prims, P.nodes, P.tris, ro, rd, h)) {
-                    term = mk(P.miss[0], P.miss[1], P.miss[2]);  // renderer.rs:61
-                    done = true;
-                } else {
-                    f3 no, nd, atten, emitted;
-                    if (surface_scatter(P.mats, h, rd, rng, no, nd, atten, emitted)) {
-                        thr = thr * atten; ro = no; rd = nd; ++ray_index;
-                    } else {
-                        term = emitted; done = true;              // renderer.rs:35
+        if (nT != 0u && (nT >= trav_min || nP + nS + nI == 0u)) {
+            // ---- TRAV: one while-while round ----
+            for (int it = 0; it < 8; ++it) {
+                const bool walking = (state == ST_TRAV) && mt.leaf_b == 0u && mt.node < mt.end;
+                if (__ballot(walking) == 0ull) break;
+                if (walking) mesh_step(n4, EPS, mt);
+            }
+            if (state == ST_TRAV && mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
+            if (state == ST_TRAV && mt.leaf_b == 0u && mt.node >= mt.end) { state = ST_TOP; walk_done = true; }
+            prof.mark(0);
+            continue;
+        }
+        if (nP != 0u && nP >= nS + nI) {
+            // ---- TOP: hittable.rs:45-58 from each lane's cursor ----
+            for (uint32_t i = 0; i < P.n_prims; ++i) {
+                const bool mine = (state == ST_TOP) && cursor == i;
+                if (__ballot(mine) == 0ull) continue;
+                cprim_t pr = prims + i;
+                if (mine) {
+                    Hit h; bool hit = false; bool advance = true;
+                    switch (pr->kind) {                                       // wave-uniform: scalar branch
+                        case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ps.ro, ps.rd, EPS, closest, h); break;
+                        case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ps.ro, ps.rd, EPS, closest, h); break;
+                        case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ps.ro, ps.rd, EPS, closest, h); break;
+                        case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, ps.ro, ps.rd, EPS, closest, h); break;
+                        default:
+                            if (walk_done) { hit = mesh_finalize(pr, t4, mt, ps.ro, ps.rd, EPS, closest, h); walk_done = false; }
+                            else { mesh_setup(pr, ps.ro, ps.rd, closest, mt); state = ST_TRAV; advance = false; }
+                            break;
                     }
+                    if (hit) { closest = h.t; best = h; any_hit = true; }
+                    if (advance) ++cursor;
                 }
             }
-            if (done) {
-                const f3 L = thr * term;
-                radiance[sidx] = make_float4(L.x, L.y, L.z, 0.0f);
-                active = false;
-            }
+            if (state == ST_TOP && cursor == P.n_prims) state = ST_SHADE;
+            prof.mark(1);
+            continue;
         }
+        // ---- SHADE + regeneration (lanes in TOP / TRAV are left untouched) ----
+        bool live = (state == ST_SHADE);
+        const bool part = live || state == ST_IDLE;
+        shade_and_regenerate(P, wc, lane, live, part, any_hit, best, ps, n_paths, n_rays, prof);
+        if (part) {
+            if (live) { state = ST_TOP; cursor = 0; closest = __builtin_inff(); any_hit = false; walk_done = false; }
+            else state = ST_IDLE;
+        }
+        prof.mark(4);
     }
+#ifdef MI355RT_STAMPS
+    if (lane == 0 && P.stats) for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
+#endif
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
     if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }
 }
@@ -648,7 +861,19 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveParams P) {
     if (p >= P.band_pixels) return;
     const float4* __restrict__ r = reinterpret_cast<const float4*>(P.radiance) + (size_t)p * P.spp;
     f3 acc = mk(0.f, 0.f, 0.f);
-    for (uint32_t s = 0; s < P.spp; ++s) { const float4 v = r[s]; acc = acc + mk(v.x, v.y, v.z); }
+    uint32_t s = 0;
+    // A lane owns a pixel, so lanes are spp*16 B apart: fetch a whole 128-B line (8 samples) per lane per
+    // step with the 8 loads in flight together, then add in sample order -- otherwise the line is evicted
+    // between its 8 uses (measured 3x over-fetch with one load per step).
+    for (; s + 8 <= P.spp; s += 8) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(r + s + k));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = acc + mk(v[k].x, v[k].y, v[k].z);
+    }
+    for (; s < P.spp; ++s) { const float4 v = r[s]; acc = acc + mk(v.x, v.y, v.z); }
     const f3 pixel = acc * P.inv_spp;
     const size_t o = (size_t)P.band_pixel0 + p;
     if (P.out_linear) { P.out_linear[3 * o] = pixel.x; P.out_linear[3 * o + 1] = pixel.y; P.out_linear[3 * o + 2] = pixel.z; }
@@ -680,9 +905,10 @@ __global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
                 if (depth == P.max_depth) break;
                 ++n_rays;
                 Hit h;
-                if (!hit_scene(prims, P.n_prims, P.nodes, P.tris, ro, rd, h)) { term = mk(P.miss[0], P.miss[1], P.miss[2]); break; }
+                if (!hit_scene<true>(prims, P.n_prims, P.nodes, P.tris, ro, rd, h)) { term = mk(P.miss[0], P.miss[1], P.miss[2]); break; }
                 f3 no, nd, atten, emitted;
-                if (!surface_scatter(P.mats, h, rd, rng, no, nd, atten, emitted)) { term = emitted; break; }
+                Prof prof; const float4 q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
+                if (!surface_scatter(P.mats, q0, h, rd, rng, no, nd, atten, emitted, prof)) { term = emitted; break; }
                 stack[3 * depth] = atten.x; stack[3 * depth + 1] = atten.y; stack[3 * depth + 2] = atten.z;
                 ro = no; rd = nd; ++depth;
             }
@@ -701,8 +927,12 @@ __global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
-int launch_render_ctr(const RenderParams& p, uint32_t grid_blocks, void* stream) {
-    hipLaunchKernelGGL(k_render_ctr, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p);
+int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blocks, void* stream) {
+    switch (variant) {
+        case KERNEL_LOCKSTEP:      hipLaunchKernelGGL(k_render_ctr<false>, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_LOCKSTEP_MESH: hipLaunchKernelGGL(k_render_ctr<true>, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        default:                   hipLaunchKernelGGL(k_render_ctr_sm, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+    }
     return (int)hipGetLastError();
 }
 int launch_resolve(const ResolveParams& p, void* stream) {
@@ -715,12 +945,15 @@ int launch_render_ref(const RefParams& p, void* stream) {
     hipLaunchKernelGGL(k_render_ref, dim3(blocks), dim3(64), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
-int query_render_ctr_occupancy(int* blocks_per_cu, int* vgprs, int* sgprs) {
+int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs) {
+    const void* fn = variant == KERNEL_LOCKSTEP ? reinterpret_cast<const void*>(k_render_ctr<false>)
+                   : variant == KERNEL_LOCKSTEP_MESH ? reinterpret_cast<const void*>(k_render_ctr<true>)
+                                                     : reinterpret_cast<const void*>(k_render_ctr_sm);
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_ctr, BLOCK_THREADS, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK_THREADS, 0);
     if (e != hipSuccess) return (int)e;
     hipFuncAttributes fa;
-    e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_render_ctr));
+    e = hipFuncGetAttributes(&fa, fn);
     if (e != hipSuccess) return (int)e;
     *blocks_per_cu = nb; *vgprs = fa.numRegs; *sgprs = 0;
     return 0;

@@ -21,10 +21,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(build.DEVICE_SO):
-            raise RuntimeError(f"{build.DEVICE_SO} is missing: the HIP extension must be built "
+        so = os.environ.get("MI355RT_DEVICE_SO", build.DEVICE_SO)     # override: diagnostic builds only (tools/)
+        if not os.path.exists(so):
+            raise RuntimeError(f"{so} is missing: the HIP extension must be built "
                                "(__graft_entry__.build()); there is no CPU fallback")
-        L = C.CDLL(build.DEVICE_SO)
+        L = C.CDLL(so)
         L.mi355rt_last_error.restype = C.c_char_p
         L.mi355rt_abi_version.restype = C.c_uint32
         L.mi355rt_render.restype = C.c_int

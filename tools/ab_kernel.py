@@ -1,0 +1,29 @@
+"""A/B of the counter-mode kernel variants / trav_min in one process (env overrides are read at set_scene)."""
+import os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import pkg
+abi, host, device = pkg("abi"), pkg("host"), pkg("device")
+import torch; torch.zeros(1, device="cuda")
+WL = {"cornell": ("data/scenes/tungsten/cornell-box/scene.json", 800, 600, 256, 30, False),
+      "semesterbild": ("data/scenes/semesterbild.json", 800, 600, 64, 30, False),
+      "veach": ("data/scenes/tungsten/veach-mis/scene.json", 1280, 720, 64, 16, False),
+      "teapot": ("data/scenes/tungsten/teapot/scene.json", 800, 600, 64, 30, True)}
+SETTINGS = [("lockstep", {"MI355RT_KERNEL": "1"})] + [(f"sm{t}", {"MI355RT_KERNEL": "2", "MI355RT_TRAV_MIN": str(t)}) for t in (8, 16, 24, 32, 48)]
+for wl in sys.argv[1:] or ["semesterbild", "teapot"]:
+    path, W, H, spp, depth, skip = WL[wl]
+    sc = host.LoadedScene(os.path.join(ROOT, path), W, H, spp, depth, skip_unknown_primitives=skip)
+    out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    ctxs = {}
+    for name, env in SETTINGS:
+        for k in ("MI355RT_KERNEL", "MI355RT_TRAV_MIN"): os.environ.pop(k, None)
+        os.environ.update(env)
+        c = device.Context(0); c.set_scene(sc, sc.camera, sc.settings); ctxs[name] = c
+    times = {n: [] for n in ctxs}; info = {}
+    for rnd in range(5):
+        for n, c in ctxs.items():
+            st = c.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
+            if rnd: times[n].append(st.render_kernel_ms)
+            info[n] = (int(out.to(torch.int64).sum().item()), st.kernel_vgprs, st.rays)
+    for n in ctxs:
+        print(f"{wl:13s} {n:10s} median {statistics.median(times[n]):8.3f} ms  min {min(times[n]):8.3f}  vgprs {info[n][1]}  rays {info[n][2]}  checksum {info[n][0]}", flush=True)
+    for c in ctxs.values(): c.close()

@@ -1,0 +1,27 @@
+"""Diagnostic: shares of wave time per section of k_render_ctr (s_memtime stamps, -DMI355RT_STAMPS build).
+Never quote this build's run time; read its SHARES (cdna_hip_programming.md section 7)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import pkg
+build = pkg("build")
+os.environ["MI355RT_DEVICE_SO"] = build.build_device_variant("stamps", ["MI355RT_STAMPS"])
+import numpy as np
+import torch
+torch.zeros(1, device="cuda")   # initialise torch's HIP context before the library's (as bench.py does)
+host, device, abi = pkg("host"), pkg("device"), pkg("abi")
+NAMES = ["BVH rounds (state machine)", "top-level list / hit_scene", "classify + finish + deal", "philox + camera + BSDF", "loop tail / vote", "-"]
+for name, path, W, H, spp, depth, skip in [("cornell", "data/scenes/tungsten/cornell-box/scene.json", 800, 600, 64, 30, False),
+                                           ("semesterbild", "data/scenes/semesterbild.json", 800, 600, 64, 30, False),
+                                           ("veach", "data/scenes/tungsten/veach-mis/scene.json", 1280, 720, 32, 16, False),
+                                           ("teapot", "data/scenes/tungsten/teapot/scene.json", 800, 600, 32, 30, True)]:
+    sc = host.LoadedScene(os.path.join(ROOT, path), W, H, spp, depth, skip_unknown_primitives=skip)
+    ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings)
+    out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    st = ctx.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
+    raw = (C.c_ulonglong * 16)()
+    assert device.lib().mi355rt_debug_read_counters(ctx._h, raw) == 0
+    acc = np.array(list(raw)[2:8], dtype=np.float64)
+    print(f"{name}: kernel {st.render_kernel_ms:.2f} ms (stamped build), rays/sample {st.rays / st.samples:.2f}")
+    for n, v in zip(NAMES, acc):
+        if v: print(f"   {n:38s} {100 * v / acc.sum():6.2f} %")
+    ctx.close()
