@@ -80,6 +80,7 @@ struct mi355rt_context {
     int cu_count = 0;
     int blocks_per_cu[3] = {0, 0, 0}, vgprs[3] = {0, 0, 0}, sgprs = 0;
     uint32_t variant = KERNEL_LOCKSTEP;  // chosen per scene in set_scene
+    uint32_t guided_mult = 16;           // run length = (left in shard) / (guided_mult * waves per shard); 16 measured best at 1/8-image launches
     uint32_t trav_min = 24;              // measured optimum 24-32 on semesterbild / teapot (tools/ab_kernel.py)
     bool have_scene = false;
     mi355rt_settings settings{};
@@ -89,6 +90,7 @@ struct mi355rt_context {
     DevBuf<DevPrim> prims; DevBuf<DevMat> mats; DevBuf<DevNode> nodes; DevBuf<DevTri> tris;
     DevBuf<uint32_t> rows; DevBuf<float> radiance; DevBuf<uint32_t> counters; DevBuf<unsigned long long> stats;
     DevBuf<float> fold_stack;
+    DevBuf<unsigned long long> wave_times; uint32_t wave_times_n = 0;   // diagnostics (MI355RT_WAVE_TIMES=1)
     std::vector<uint32_t> rows_host;     // source of the async row-table upload; must outlive the copy
     bool rows_valid = false;             // ctx->rows already holds rows_host (same selection as the last call)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -213,6 +215,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         if (v >= 0 && v <= 2 && (v != KERNEL_LOCKSTEP || !has_mesh)) ctx->variant = (uint32_t)v;
     }
     ctx->trav_min = 24;
+    if (const char* e = std::getenv("MI355RT_GUIDED_MULT")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->guided_mult = (uint32_t)v; }
     if (const char* e = std::getenv("MI355RT_TRAV_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->trav_min = (uint32_t)v; }
     return MI355RT_OK;
 }
@@ -259,7 +262,7 @@ void mi355rt_context_destroy(mi355rt_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     ctx->prims.release(); ctx->mats.release(); ctx->nodes.release(); ctx->tris.release(); ctx->rows.release();
-    ctx->radiance.release(); ctx->counters.release(); ctx->stats.release(); ctx->fold_stack.release();
+    ctx->radiance.release(); ctx->counters.release(); ctx->stats.release(); ctx->fold_stack.release(); ctx->wave_times.release();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->pool) if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -334,13 +337,14 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         const uint64_t spp = st.samples_per_pixel;
         const uint64_t total_pixels = (uint64_t)n_rows * st.width;
         uint64_t ws_cap = (opt && opt->workspace_bytes) ? opt->workspace_bytes : (4ull << 30);
-        uint64_t max_samples = std::min<uint64_t>(ws_cap / 16, (1ull << 31) - BATCH_SAMPLES);
+        uint64_t max_samples = std::min<uint64_t>(ws_cap / 16, (1ull << 31) - 2 * BATCH_MAX);
         if (max_samples < spp) return fail(MI355RT_ERR_INVALID, "workspace_bytes too small for one pixel (needs spp * 16 bytes)");
         const uint64_t band_pixels_max = std::min<uint64_t>(max_samples / spp, total_pixels);
         n_bands = (uint32_t)((total_pixels + band_pixels_max - 1) / band_pixels_max);
         if ((rc = ctx->radiance.ensure((size_t)(band_pixels_max * spp * 4)))) return rc;
-        if ((rc = ctx->counters.ensure(n_bands))) return rc;
-        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, (size_t)n_bands * sizeof(uint32_t), stream));
+        const size_t ctr_words = (size_t)WORK_SHARDS * WORK_SHARD_STRIDE;            // per band
+        if ((rc = ctx->counters.ensure((size_t)n_bands * ctr_words))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, (size_t)n_bands * ctr_words * sizeof(uint32_t), stream));
 
         RenderParams p{};
         p.prims = ctx->prims.p; p.mats = ctx->mats.p; p.nodes = ctx->nodes.p; p.tris = ctx->tris.p; p.rows = ctx->rows.p;
@@ -361,10 +365,19 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
             const uint64_t p0 = (uint64_t)b * band_pixels_max;
             const uint64_t np = std::min<uint64_t>(band_pixels_max, total_pixels - p0);
             p.band_pixel0 = (uint32_t)p0; p.band_samples = (uint32_t)(np * spp);
-            p.n_batches = (p.band_samples + BATCH_SAMPLES - 1) / BATCH_SAMPLES;
-            p.batch_counter = ctx->counters.p + b;
+            p.batch_counter = ctx->counters.p + (size_t)b * ctr_words;
+            p.shard_samples = (p.band_samples + WORK_SHARDS - 1) / WORK_SHARDS;
             const uint32_t waves_per_block = BLOCK_THREADS / 64;
-            const uint32_t grid = std::max(1u, std::min(resident, (p.n_batches + waves_per_block - 1) / waves_per_block));
+            const uint32_t min_runs = (p.band_samples + BATCH_MIN - 1) / BATCH_MIN;           // never more waves than minimum-size runs
+            const uint32_t grid = std::max(1u, std::min(resident, (min_runs + waves_per_block - 1) / waves_per_block));
+            p.guided_div = std::max(1u, ctx->guided_mult * grid * waves_per_block / WORK_SHARDS);
+            p.wave_times = nullptr;
+            if (std::getenv("MI355RT_WAVE_TIMES")) {
+                ctx->wave_times_n = grid * waves_per_block;
+                if ((rc = ctx->wave_times.ensure((size_t)ctx->wave_times_n * 3))) return rc;
+                HIP_TRY(hipMemsetAsync(ctx->wave_times.p, 0, (size_t)ctx->wave_times_n * 24, stream));
+                p.wave_times = ctx->wave_times.p;
+            }
             grid_blocks = std::max(grid_blocks, grid);
             r.band_pixel0 = (uint32_t)p0; r.band_pixels = (uint32_t)np;
             hipEvent_t pe0 = nullptr, pe1 = nullptr, pe2 = nullptr;
@@ -402,6 +415,15 @@ int mi355rt_debug_read_counters(mi355rt_context* ctx, unsigned long long* out16)
     if (!ctx || !out16 || !ctx->stats.p) return fail(MI355RT_ERR_INVALID, "no counters");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpy(out16, ctx->stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MI355RT_OK;
+}
+
+int mi355rt_debug_read_wave_times(mi355rt_context* ctx, unsigned long long* out, uint32_t capacity_waves, uint32_t* n_waves) {
+    if (!ctx || !out || !n_waves) return fail(MI355RT_ERR_INVALID, "null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t n = std::min(capacity_waves, ctx->wave_times_n);
+    if (n) HIP_TRY(hipMemcpy(out, ctx->wave_times.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    *n_waves = n;
     return MI355RT_OK;
 }
 

@@ -44,22 +44,34 @@ static_assert(sizeof(DevTri) == 48, "DevTri");
 
 struct DevCamera { float position[3], forward[3], right[3], true_up[3], half_width, half_height; };
 
-constexpr uint32_t BATCH_SAMPLES = 1024;   // paths a wave claims per global atomic
+#ifndef MI355RT_BATCH_MIN
+#define MI355RT_BATCH_MIN 128
+#endif
+#ifndef MI355RT_BATCH_MAX
+#define MI355RT_BATCH_MAX 256
+#endif
+// 256 = one pixel's samples at the headline 256 spp: the lanes of a wave then share the camera ray and the first
+// hit, so whole accept blocks are skipped wave-wide (measured: 2048 -> 27.1 ms, 512 -> 26.1, 256 -> 25.8 on cornell).
+constexpr uint32_t BATCH_MIN = MI355RT_BATCH_MIN, BATCH_MAX = MI355RT_BATCH_MAX;   // paths a wave claims per global atomic (guided self-scheduling)
 constexpr uint32_t BLOCK_THREADS = 256;
+constexpr uint32_t WORK_SHARDS = 8;            // one work counter per XCD (power of two)
+constexpr uint32_t WORK_SHARD_STRIDE = 32;     // u32 words between counters: one 128-B line each
 
 struct RenderParams {
     const DevPrim* prims; const DevMat* mats; const DevNode* nodes; const DevTri* tris;
     const uint32_t* rows;        // local row -> absolute y
     float* radiance;             // float4 per band sample
-    uint32_t* batch_counter;     // zeroed before each band
+    uint32_t* batch_counter;     // WORK_SHARDS counters (WORK_SHARD_STRIDE words apart): next unclaimed sample of each shard; zeroed per band
     unsigned long long* stats;   // [0] = paths started, [1] = rays traced
+    unsigned long long* wave_times;  // diagnostic builds only: per wave {start, end (100 MHz ticks), paths}; null otherwise
     uint32_t n_prims, n_mats;
     float miss[3];
     DevCamera cam;
     uint32_t width, height, spp, max_depth;
     uint32_t band_pixel0;        // first local pixel (row-major over the selected rows) of this band
     uint32_t band_samples;       // band pixels * spp  (< 2^31)
-    uint32_t n_batches;
+    uint32_t guided_div;         // run length = (left in the shard) / guided_div
+    uint32_t shard_samples;      // samples per shard: ceil(band_samples / WORK_SHARDS)
     uint32_t seed_lo, seed_hi;
     uint32_t spp_mul, spp_shift, width_mul, width_shift;   // magic pairs for n / spp and n / width (n < 2^31)
     uint32_t trav_min;           // state-machine kernel: run BVH rounds while at least this many lanes are walking

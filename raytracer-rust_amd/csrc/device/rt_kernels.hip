@@ -605,21 +605,38 @@ DI uint32_t wave_sum(uint32_t v) {
 // n / d for n < 2^31 with a host-computed magic pair (mul == 0 means d == 1): q = umulhi(n, mul) >> shift.
 DI uint32_t fastdiv(uint32_t n, uint32_t mul, uint32_t shift) { return mul ? (__umulhi(n, mul) >> shift) : n; }
 
-// Wave-uniform cursor over the band's sample indices.  A wave claims BATCH_SAMPLES consecutive indices
-// with one global atomic and deals them to idle lanes with ballot + mbcnt.
+// Wave-uniform cursor over the band's sample indices.  A wave claims a run of consecutive indices with one
+// global atomic and deals them to idle lanes with ballot + mbcnt.
+//  * The band is cut into WORK_SHARDS contiguous ranges, each with its own counter on its own cache line.
+//    A wave starts on the shard of its XCD (HW_REG_XCC_ID; used for speed only) and moves to the next shard
+//    when one runs dry (work stealing), so one hot word never serialises all 6 k waves of the chip
+//    (measured: a single counter saturates near 88 atomics/us and made short runs 30 % slower).
+//  * Run length follows guided self-scheduling: (what was left in the shard at the wave's previous claim)
+//    / guided_div, clamped to [BATCH_MIN, BATCH_MAX] -- long runs while there is plenty of work (few atomics,
+//    coherent primary rays), short runs at the end so that all waves drain together.  This matters when one
+//    image is split across 8 GPUs and a launch lasts only a few ms.
+DI uint32_t xcc_id() { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & (WORK_SHARDS - 1u); }
 struct WorkCursor {
     uint32_t next = 0, end = 0; bool no_more = false;
+    uint32_t shard = 0, dry = 0, seen = 0;      // current shard, consecutive dry shards, last counter value seen in it
+    DI void init() { shard = xcc_id(); }
     DI bool exhausted() const { return no_more && next == end; }
     // Lanes with want == true get a sample index (returns true and sets sidx); others / surplus stay idle.
     DI bool deal(const RenderParams& P, bool want, uint32_t lane, uint32_t& sidx) {
         const uint64_t idle = __ballot(want);
         if (idle == 0ull) return false;
-        if (next == end && !no_more) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(P.batch_counter, 1u);
-            b = __builtin_amdgcn_readfirstlane(b);
-            if (b >= P.n_batches) no_more = true;
-            else { next = b * BATCH_SAMPLES; end = min(next + BATCH_SAMPLES, P.band_samples); }
+        while (next == end && !no_more) {
+            const uint32_t base = shard * P.shard_samples;
+            const uint32_t len = min(P.shard_samples, P.band_samples > base ? P.band_samples - base : 0u);
+            const uint32_t rem = len > seen ? len - seen : 0u;
+            const uint32_t size = min(max(rem / P.guided_div, BATCH_MIN), BATCH_MAX);
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(P.batch_counter + shard * WORK_SHARD_STRIDE, size);
+            start = __builtin_amdgcn_readfirstlane(start);
+            if (start >= len) {                              // shard is dry: steal from the next one
+                shard = (shard + 1u) & (WORK_SHARDS - 1u); seen = 0;
+                if (++dry == WORK_SHARDS) no_more = true;
+            } else { next = base + start; end = base + min(start + size, len); seen = start + size; dry = 0; }
         }
         const uint32_t take = min((uint32_t)__popcll(idle), end - next);
         bool got = false;
@@ -735,12 +752,15 @@ template <bool HAS_MESH>
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr(const RenderParams P) {
     cprim_t prims = (cprim_t)(P.prims);
     const uint32_t lane = threadIdx.x & 63u;
-    WorkCursor wc;
+    WorkCursor wc; wc.init();
     PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
     ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
     bool live = false;
     uint32_t n_paths = 0, n_rays = 0;
     Prof prof; prof.begin();
+#ifdef MI355RT_STAMPS
+    const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (;;) {
         Hit h; bool hit = false;
         h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
@@ -751,6 +771,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr(con
     }
 #ifdef MI355RT_STAMPS
     if (lane == 0 && P.stats) for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
+    if (P.wave_times) {
+        const unsigned long long t_wave1 = __builtin_amdgcn_s_memrealtime();
+        const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        const uint32_t np = wave_sum(n_paths);
+        if (lane == 0) { P.wave_times[3 * (size_t)wid] = t_wave0; P.wave_times[3 * (size_t)wid + 1] = t_wave1; P.wave_times[3 * (size_t)wid + 2] = np; }
+    }
 #endif
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
     if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }
@@ -778,7 +804,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
     const uint32_t lane = threadIdx.x & 63u;
-    WorkCursor wc;
+    WorkCursor wc; wc.init();
     PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
     ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
     uint32_t state = ST_IDLE, cursor = 0;

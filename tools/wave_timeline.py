@@ -1,0 +1,25 @@
+"""Diagnostic: per-wave start/end times of k_render_ctr (stamps build) -> ramp-up and drain tail."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import pkg
+build = pkg("build")
+os.environ["MI355RT_DEVICE_SO"] = build.build_device_variant("stamps", ["MI355RT_STAMPS"])
+os.environ["MI355RT_WAVE_TIMES"] = "1"
+import numpy as np, torch
+torch.zeros(1, device="cuda")
+host, device, abi = pkg("host"), pkg("device"), pkg("abi")
+sc = host.LoadedScene(os.path.join(ROOT, "data/scenes/tungsten/cornell-box/scene.json"), 800, 600, 256, 30)
+ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings)
+out = torch.zeros(800 * 600, dtype=torch.int32, device="cuda")
+for parts in (1, 8):
+    opt = abi.Options.make(strip_rows=5, n_parts=parts, part=0)
+    for _ in range(3): st = ctx.render(out.data_ptr(), None, opt, None, want_stats=True)
+    buf = np.zeros(3 * 8192, np.uint64); n = C.c_uint32()
+    assert device.lib().mi355rt_debug_read_wave_times(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 8192, C.byref(n)) == 0
+    w = buf[:3 * n.value].reshape(-1, 3).astype(np.float64)
+    t0 = w[:, 0].min(); start = (w[:, 0] - t0) / 100.0; end = (w[:, 1] - t0) / 100.0     # microseconds (100 MHz)
+    print(f"parts={parts}: kernel {st.render_kernel_ms:.3f} ms, waves {n.value}, paths/wave mean {w[:,2].mean():.0f} min {w[:,2].min():.0f} max {w[:,2].max():.0f}")
+    print("   wave start  us: p50 %.0f p99 %.0f max %.0f" % tuple(np.percentile(start, [50, 99, 100])))
+    print("   wave end    us: p1 %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(end, [1, 10, 50, 90, 99, 100])))
+    busy = (w[:, 1] - w[:, 0]).sum() / 100.0
+    print("   sum(wave lifetimes) / (waves * makespan) = %.3f" % (busy / (n.value * end.max())))
