@@ -68,11 +68,20 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    # Rehearsal on a one-GPU box (MI355RT_BENCH_REHEARSE=1): every rank shares cuda:0 and the gather goes through
+    # gloo on host copies, because RCCL refuses two ranks on one GPU.  It checks the multi-rank plumbing only;
+    # its numbers mean nothing and the JSON says so.
+    rehearse = os.environ.get("MI355RT_BENCH_REHEARSE") == "1" and world > 1
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     path, W, H, spp, depth, skip_unknown = WORKLOADS[args.workload]
     scene = host.LoadedScene(os.path.join(ROOT, path), W, H, spp, depth, skip_unknown_primitives=skip_unknown)   # product loader (C++)
@@ -94,7 +103,7 @@ def main():
     def step():
         nonlocal image
         ctx.render(local.data_ptr(), None, opt, stream)               # enqueue only: no host sync inside
-        image = rtdist.gather_image(local, plan, rank)
+        image = rtdist.gather_image(local.cpu() if rehearse else local, plan, rank)
 
     for _ in range(args.warmup):
         step()
@@ -108,7 +117,7 @@ def main():
     k_render_ms, k_resolve_ms, launches = ctx.read_timing()
     ctx.set_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -137,6 +146,8 @@ def main():
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get(args.workload, {}).get("k_render_ctr_hbm_bytes_per_launch")
+                if traffic is not None:          # measured on the whole image in one launch; a rank renders local_samples of it
+                    traffic = int(traffic * local_samples / total_samples)
             except Exception:
                 traffic = None
         result = {
@@ -154,8 +165,11 @@ def main():
                          "launches_timed": launches, "samples_per_launch": local_samples,
                          "note": "scene records are SGPR/L2 resident, so algorithmic bytes never reach HBM; the binding unit is the f32 VALU"},
             "cpu_baseline": cpu_baseline,
+            **({"rehearsal": "all ranks on cuda:0 over gloo -- plumbing check only, NOT a measurement"} if rehearse else {}),
             "kernel": {"vgprs": st.kernel_vgprs, "grid_blocks": st.grid_blocks, "block_threads": st.block_threads, "bands": st.bands},
         }
+        if image is not None:
+            result["image_checksum"] = int(image.to(torch.int64).sum().item())      # identical for every N (RNG keyed by absolute row)
         if args.save_png and image is not None:
             import numpy as np
             host.write_png(args.save_png, image.cpu().numpy().astype(np.uint32), W, H)
