@@ -816,6 +816,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
     uint32_t n_paths = 0, n_rays = 0;
     Prof prof; prof.begin();
     const uint32_t trav_min = P.trav_min;
+#ifdef MI355RT_STAMPS
+    unsigned long long c_exec[4] = {0, 0, 0, 0}, c_lanes[4] = {0, 0, 0, 0};    // 0 inner steps, 1 leaf phases, 2 TOP passes, 3 SHADE passes
+#define MI355RT_COUNT(i, mask) do { c_exec[i] += 1; c_lanes[i] += (unsigned long long)__popcll(mask); } while (0)
+#else
+#define MI355RT_COUNT(i, mask) do {} while (0)
+#endif
 
     for (;;) {
         const uint32_t nT = (uint32_t)__popcll(__ballot(state == ST_TRAV));
@@ -828,9 +834,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
             // ---- TRAV: one while-while round ----
             for (int it = 0; it < 8; ++it) {
                 const bool walking = (state == ST_TRAV) && mt.leaf_b == 0u && mt.node < mt.end;
-                if (__ballot(walking) == 0ull) break;
+                const uint64_t wm = __ballot(walking);
+                if (wm == 0ull) break;
+                MI355RT_COUNT(0, wm);
                 if (walking) mesh_step(n4, EPS, mt);
             }
+            MI355RT_COUNT(1, __ballot(state == ST_TRAV && mt.leaf_b != 0u));
             if (state == ST_TRAV && mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
             if (state == ST_TRAV && mt.leaf_b == 0u && mt.node >= mt.end) { state = ST_TOP; walk_done = true; }
             prof.mark(0);
@@ -838,6 +847,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
         }
         if (nP != 0u && nP >= nS + nI) {
             // ---- TOP: hittable.rs:45-58 from each lane's cursor ----
+            MI355RT_COUNT(2, __ballot(state == ST_TOP));
             for (uint32_t i = 0; i < P.n_prims; ++i) {
                 const bool mine = (state == ST_TOP) && cursor == i;
                 if (__ballot(mine) == 0ull) continue;
@@ -865,6 +875,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
         // ---- SHADE + regeneration (lanes in TOP / TRAV are left untouched) ----
         bool live = (state == ST_SHADE);
         const bool part = live || state == ST_IDLE;
+        MI355RT_COUNT(3, __ballot(part));
         shade_and_regenerate(P, wc, lane, live, part, any_hit, best, ps, n_paths, n_rays, prof);
         if (part) {
             if (live) { state = ST_TOP; cursor = 0; closest = __builtin_inff(); any_hit = false; walk_done = false; }
@@ -873,7 +884,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
         prof.mark(4);
     }
 #ifdef MI355RT_STAMPS
-    if (lane == 0 && P.stats) for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
+    if (lane == 0 && P.stats) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
+        for (int i = 0; i < 4; ++i) { atomicAdd(&P.stats[8 + 2 * i], c_exec[i]); atomicAdd(&P.stats[9 + 2 * i], c_lanes[i]); }
+    }
 #endif
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
     if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }

@@ -24,4 +24,10 @@ for name, path, W, H, spp, depth, skip in [("cornell", "data/scenes/tungsten/cor
     print(f"{name}: kernel {st.render_kernel_ms:.2f} ms (stamped build), rays/sample {st.rays / st.samples:.2f}")
     for n, v in zip(NAMES, acc):
         if v: print(f"   {n:38s} {100 * v / acc.sum():6.2f} %")
+    blk = list(raw)[8:16]
+    if sum(blk):
+        rays = st.rays
+        for i, n in enumerate(["inner-node steps", "leaf phases", "TOP passes", "SHADE passes"]):
+            e, l = blk[2 * i], blk[2 * i + 1]
+            if e: print(f"   {n:18s} executions per 64 rays {e / (rays / 64):7.2f}   mean lanes {l / e:5.1f}")
     ctx.close()
