@@ -461,13 +461,17 @@ DI float beckmann_lambda(float a, float x) {                                    
 
 // Result of one surface interaction (renderer.rs:26-36): either the path goes on (scattered ray +
 // attenuation) or it ends with `emitted` (scatter -> None).
+// Split in two so that the counter-mode kernels can run the unit-ball rejection of the Lambert-style bounce
+// wave-cooperatively between the halves: scatter_pre() decides everything except that direction (it sets
+// `diffuse`), diffuse_finish() turns the accepted unit-ball point into the scattered ray (material.rs:54-62).
 template <class Rng>
-DI bool surface_scatter(const DevMat* __restrict__ mats, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted, Prof& prof) {
+DI bool scatter_pre(const DevMat* __restrict__ mats, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted, bool& diffuse_out) {
     const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
     const uint32_t kind = __float_as_uint(q0.x);
     const f3 albedo = mk(q0.y, q0.z, q0.w);
     const bool front_face = (h.mat_ff >> 31) != 0;
     emitted = mk(0.f, 0.f, 0.f);
+    diffuse_out = false;
     if (kind == MI355RT_MAT_EMISSIVE) { emitted = albedo; return false; }         // material.rs:179-191
     if (kind == MI355RT_MAT_NULL) return false;                                   // material.rs:239-251
     rng.begin_scatter();
@@ -568,16 +572,25 @@ DI bool surface_scatter(const DevMat* __restrict__ mats, const float4 q0, const 
         new_o = h.p + n * EPS;
         new_d = normalized(normalized(l));
     }
-    prof.mark(2);
-    if (diffuse) {                                                                 // material.rs:54-62
+    diffuse_out = diffuse;
+    return true;
+}
+DI void diffuse_finish(const Hit& h, f3 p, f3& new_o, f3& new_d) {                  // material.rs:54-62
+    f3 dir = h.n + normalized(p);
+    if (near_zero(dir)) dir = h.n;
+    new_o = h.p + h.n * EPS;
+    new_d = normalized(normalized(dir));                                           // .normalized() then Ray::new
+}
+// Sequential composition (reference-stream replay kernel): random_in_unit_sphere as the plain loop, vec3.rs:54-61.
+template <class Rng>
+DI bool surface_scatter(const DevMat* __restrict__ mats, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted) {
+    bool diffuse = false;
+    if (!scatter_pre(mats, q0, h, rd_in, rng, new_o, new_d, atten, emitted, diffuse)) return false;
+    if (diffuse) {
         f3 p; uint32_t j = 0;
-        do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));              // vec3.rs:54-61
-        f3 dir = h.n + normalized(p);
-        if (near_zero(dir)) dir = h.n;
-        new_o = h.p + h.n * EPS;
-        new_d = normalized(normalized(dir));                                       // .normalized() then Ray::new
+        do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));
+        diffuse_finish(h, p, new_o, new_d);
     }
-    prof.mark(3);
     return true;
 }
 
@@ -669,6 +682,49 @@ struct PathState {
     RngCtr rng;
 };
 
+// random_in_unit_sphere (vec3.rs:54-61) for the whole wave at once, counter mode.  Try 0 comes from the event's
+// block 0 (already in rng.b0).  Lanes whose try 0 failed become OWNERS of a retry request; then every lane of
+// the wave -- busy or not -- is a WORKER: with n owners, G = 2^floor(log2(64 / n)) workers serve each owner and
+// evaluate its tries jbase .. jbase+G-1 in parallel (the owner's counters arrive through ds_bpermute; a draw is a
+// pure function of (key, x, s, ray, try), so any lane can compute it).  The owner takes the FIRST accepted try of
+// its segment of the ballot, i.e. exactly the try the sequential loop would have stopped at.  Typically two
+// rounds instead of E[max over 64 lanes of a geometric(0.52)] ~ 7.7 iterations of a mostly idle wave.
+// Must be called in wave-uniform control flow.
+DI int lane_shfl(int v, uint32_t src_lane) { return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), v); }
+DI float lane_shfl(float v, uint32_t src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v))); }
+DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
+    f3 p = mk(u32_to_range11(rng.b0[1]), u32_to_range11(rng.b0[2]), u32_to_range11(rng.b0[3]));   // try 0
+    bool need = diffuse && !(len2(p) < 1.0f);
+    uint32_t jbase = 1;
+    for (;;) {
+        const uint64_t m = __ballot(need);
+        if (m == 0ull) break;
+        const uint32_t n = (uint32_t)__popcll(m);
+        const uint32_t lg = 6u - (n <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(n - 1u));   // G = 2^lg = largest power of two <= 64 / n workers per owner
+        const uint32_t r = mbcnt64(m);                                             // owners below this lane
+        // table: lane t holds the lane id of owner number t (a full permutation keeps every lane enabled)
+        const int tab = __builtin_amdgcn_ds_permute((int)((need ? r : n + (lane - r)) << 2), (int)lane);
+        const uint32_t orank = lane >> lg;
+        const bool worker = orank < n;
+        const uint32_t olane = (uint32_t)lane_shfl(tab, worker ? orank : 0u);
+        const uint32_t ok0 = (uint32_t)lane_shfl((int)rng.k0, olane), ok1 = (uint32_t)lane_shfl((int)rng.k1, olane);
+        const uint32_t ox = (uint32_t)lane_shfl((int)rng.x, olane), os = (uint32_t)lane_shfl((int)rng.s, olane);
+        const uint32_t oray = (uint32_t)lane_shfl((int)rng.ray, olane), oj = (uint32_t)lane_shfl((int)jbase, olane);
+        uint32_t w[4];
+        philox4x32_10(ok0, ok1, ox, os, oray, oj + (lane & ((1u << lg) - 1u)), w);
+        const f3 q = mk(u32_to_range11(w[1]), u32_to_range11(w[2]), u32_to_range11(w[3]));
+        const uint64_t acc = __ballot(worker && (len2(q) < 1.0f));
+        const uint32_t seg_lo = r << lg;                                           // my segment of the ballot (owners only)
+        const uint64_t segmask = (lg == 6u) ? ~0ull : ((1ull << (1u << lg)) - 1ull);
+        const uint64_t seg = need ? ((acc >> seg_lo) & segmask) : 0ull;
+        const bool found = seg != 0ull;
+        const uint32_t src = found ? seg_lo + (uint32_t)__builtin_ctzll(seg) : lane;
+        const float qx = lane_shfl(q.x, src), qy = lane_shfl(q.y, src), qz = lane_shfl(q.z, src);
+        if (need) { if (found) { p = mk(qx, qy, qz); need = false; } else jbase += (1u << lg); }
+    }
+    return p;
+}
+
 // The shading half of one trace_ray level (renderer.rs:26-36) plus path regeneration, for every lane of the
 // wave at once.  On entry `live` lanes carry a finished intersection (`hit`, `h`); on exit `live` lanes carry
 // the next ray to trace.  Order: finish paths that end without scattering (miss / emitter / null) ->
@@ -695,6 +751,8 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
     bool fresh = false;
     if (wc.deal(P, can_take && !live, lane, ps.sidx)) { start_path(P, ps.sidx, ps.rng, ps.px, ps.py); fresh = true; live = true; ++n_paths; }
     if (__ballot(live) == 0ull) return !wc.exhausted();
+    bool diffuse = false, scattered = false;
+    f3 no = mk(0.f, 0.f, 0.f), nd = mk(0.f, 0.f, 1.f), atten = mk(0.f, 0.f, 0.f), emitted = mk(0.f, 0.f, 0.f);
     if (live) {
         if (!fresh) ps.rng.next_event();
         ps.rng.load_block0();
@@ -705,20 +763,25 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
             ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
             if (P.max_depth == 0u) { radiance[ps.sidx] = make_float4(0.f, 0.f, 0.f, 0.f); live = false; }   // depth == 0 -> BLACK
         } else {
-            f3 no, nd, atten, emitted;
-            if (surface_scatter(P.mats, q0, h, ps.rd, ps.rng, no, nd, atten, emitted, prof)) {
-                ps.thr = ps.thr * atten; ps.ro = no; ps.rd = nd; ++ps.ray_index;
-                if (ps.ray_index == P.max_depth) {                                       // next level has depth == 0 (renderer.rs:20-22)
-                    const f3 L = ps.thr * mk(0.f, 0.f, 0.f);
-                    radiance[ps.sidx] = make_float4(L.x, L.y, L.z, 0.0f); live = false;
-                }
-            } else {                                                                     // absorbed: scatter -> None (renderer.rs:35)
-                const f3 L = ps.thr * emitted;
+            scattered = scatter_pre(P.mats, q0, h, ps.rd, ps.rng, no, nd, atten, emitted, diffuse);
+        }
+    }
+    prof.mark(5);
+    const f3 ball = unit_ball_cooperative(diffuse, ps.rng, lane);                        // whole wave, uniform control flow
+    if (live && !fresh) {
+        if (scattered) {
+            if (diffuse) diffuse_finish(h, ball, no, nd);
+            ps.thr = ps.thr * atten; ps.ro = no; ps.rd = nd; ++ps.ray_index;
+            if (ps.ray_index == P.max_depth) {                                           // next level has depth == 0 (renderer.rs:20-22)
+                const f3 L = ps.thr * mk(0.f, 0.f, 0.f);
                 radiance[ps.sidx] = make_float4(L.x, L.y, L.z, 0.0f); live = false;
             }
+        } else {                                                                         // absorbed: scatter -> None (renderer.rs:35)
+            const f3 L = ps.thr * emitted;
+            radiance[ps.sidx] = make_float4(L.x, L.y, L.z, 0.0f); live = false;
         }
-        if (live) ++n_rays;
     }
+    if (live) ++n_rays;
     prof.mark(3);
     return true;
 }
@@ -726,6 +789,12 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
 // Register budget per kernel, as waves per SIMD (A/B: tools/ab.py).  The lockstep kernel is VALU-issue bound
 // and gains from 6 waves/SIMD even with a few spills; the state-machine kernel keeps its hot BVH state in
 // registers and loses when capped.
+#ifndef MI355RT_INLINE_STEPS
+#define MI355RT_INLINE_STEPS 1
+#endif
+#ifndef MI355RT_TRAV_BIAS
+#define MI355RT_TRAV_BIAS 2
+#endif
 #ifndef MI355RT_OCC_LOCKSTEP
 #define MI355RT_OCC_LOCKSTEP 6
 #endif
@@ -831,11 +900,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
         if (nT + nP + nS + nI == 0u) break;
 
         if (nT != 0u && (nT >= trav_min || nP + nS + nI == 0u)) {
-            // ---- TRAV: one while-while round ----
-            for (int it = 0; it < 8; ++it) {
+            // ---- TRAV: one while-while round.  Inner-node steps and the leaf phase are themselves voted: step
+            //      while at least as many lanes are walking as have a leaf pending, then test the leaves ----
+#ifndef MI355RT_TRAV_STEPS
+#define MI355RT_TRAV_STEPS 16
+#endif
+            for (int it = 0; it < MI355RT_TRAV_STEPS; ++it) {
                 const bool walking = (state == ST_TRAV) && mt.leaf_b == 0u && mt.node < mt.end;
                 const uint64_t wm = __ballot(walking);
-                if (wm == 0ull) break;
+                const uint64_t lm = __ballot(state == ST_TRAV && mt.leaf_b != 0u);
+                if (wm == 0ull || __popcll(wm) * MI355RT_TRAV_BIAS < __popcll(lm)) break;
                 MI355RT_COUNT(0, wm);
                 if (walking) mesh_step(n4, EPS, mt);
             }
@@ -860,8 +934,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
                         case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ps.ro, ps.rd, EPS, closest, h); break;
                         case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, ps.ro, ps.rd, EPS, closest, h); break;
                         default:
+                            if (!walk_done) {
+                                // Most rays leave a mesh within a few box tests (they miss its root or upper boxes):
+                                // take those steps right here so that only long walks pay a TRAV / TOP round trip.
+                                mesh_setup(pr, ps.ro, ps.rd, closest, mt);
+#pragma unroll 1
+                                for (int k = 0; k < MI355RT_INLINE_STEPS; ++k) {
+                                    if (mt.leaf_b != 0u || mt.node >= mt.end) break;
+                                    mesh_step(n4, EPS, mt);
+                                }
+                                if (mt.leaf_b == 0u && mt.node >= mt.end) walk_done = true;   // walked off the tree without meeting a leaf
+                            }
                             if (walk_done) { hit = mesh_finalize(pr, t4, mt, ps.ro, ps.rd, EPS, closest, h); walk_done = false; }
-                            else { mesh_setup(pr, ps.ro, ps.rd, closest, mt); state = ST_TRAV; advance = false; }
+                            else { state = ST_TRAV; advance = false; }
                             break;
                     }
                     if (hit) { closest = h.t; best = h; any_hit = true; }
@@ -947,8 +1032,8 @@ __global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
                 Hit h;
                 if (!hit_scene<true>(prims, P.n_prims, P.nodes, P.tris, ro, rd, h)) { term = mk(P.miss[0], P.miss[1], P.miss[2]); break; }
                 f3 no, nd, atten, emitted;
-                Prof prof; const float4 q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
-                if (!surface_scatter(P.mats, q0, h, rd, rng, no, nd, atten, emitted, prof)) { term = emitted; break; }
+                const float4 q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
+                if (!surface_scatter(P.mats, q0, h, rd, rng, no, nd, atten, emitted)) { term = emitted; break; }
                 stack[3 * depth] = atten.x; stack[3 * depth + 1] = atten.y; stack[3 * depth + 2] = atten.z;
                 ro = no; rd = nd; ++depth;
             }

@@ -11,9 +11,9 @@ torch.zeros(1, device="cuda")   # initialise torch's HIP context before the libr
 host, device, abi = pkg("host"), pkg("device"), pkg("abi")
 NAMES = ["BVH rounds (state machine)", "top-level list / hit_scene", "classify + finish + deal", "philox + camera + BSDF", "loop tail / vote", "-"]
 for name, path, W, H, spp, depth, skip in [("cornell", "data/scenes/tungsten/cornell-box/scene.json", 800, 600, 64, 30, False),
-                                           ("semesterbild", "data/scenes/semesterbild.json", 800, 600, 64, 30, False),
+                                           ("semesterbild", "data/scenes/semesterbild.json", 800, 600, 256, 30, False),
                                            ("veach", "data/scenes/tungsten/veach-mis/scene.json", 1280, 720, 32, 16, False),
-                                           ("teapot", "data/scenes/tungsten/teapot/scene.json", 800, 600, 32, 30, True)]:
+                                           ("teapot", "data/scenes/tungsten/teapot/scene.json", 800, 600, 256, 30, True)]:
     sc = host.LoadedScene(os.path.join(ROOT, path), W, H, spp, depth, skip_unknown_primitives=skip)
     ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings)
     out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
