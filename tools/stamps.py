@@ -9,7 +9,7 @@ import numpy as np
 import torch
 torch.zeros(1, device="cuda")   # initialise torch's HIP context before the library's (as bench.py does)
 host, device, abi = pkg("host"), pkg("device"), pkg("abi")
-NAMES = ["BVH rounds (state machine)", "top-level list / hit_scene", "classify + finish + deal", "philox + camera + BSDF", "loop tail / vote", "-"]
+NAMES = ["BVH rounds (state machine)", "top-level list / hit_scene", "classify + finish + deal", "cooperative rejection + finish", "loop tail / vote", "philox + camera + material switch"]
 for name, path, W, H, spp, depth, skip in [("cornell", "data/scenes/tungsten/cornell-box/scene.json", 800, 600, 64, 30, False),
                                            ("semesterbild", "data/scenes/semesterbild.json", 800, 600, 256, 30, False),
                                            ("veach", "data/scenes/tungsten/veach-mis/scene.json", 1280, 720, 32, 16, False),
