@@ -158,6 +158,29 @@ int flatten_mesh(const mi355rt_scene* sc, const mi355rt_mesh& m, std::vector<Dev
     return MI355RT_OK;
 }
 
+// The 6 world normals a cube hit can produce (cube.rs:105-136): normalized(world_to_object^T * (+-e_k, 0)) with
+// exactly the device's operation order (xform_normal + normalized in rt_kernels.hip; this file is compiled
+// with -ffp-contract=off too), so the kernel can select instead of recomputing sqrt and divide per hit.
+void cube_normal_table(float* d) {
+    const float EPS = 1e-4f;
+    for (int k = 0; k < 3; ++k) for (int sgn = 0; sgn < 2; ++sgn) {
+        volatile float n[3] = {0.0f, 0.0f, 0.0f};
+        n[k] = sgn ? -1.0f : 1.0f;
+        float v[3];
+        for (int r = 0; r < 3; ++r) {
+            volatile float a = d[4 * r + 0] * n[0], b = d[4 * r + 1] * n[1], c = d[4 * r + 2] * n[2];
+            volatile float s1 = a + b; volatile float s2 = s1 + c; volatile float s3 = s2 + d[31 + r];
+            v[r] = s3;
+        }
+        volatile float xx = v[0] * v[0], yy = v[1] * v[1], zz = v[2] * v[2];
+        volatile float l2a = xx + yy; volatile float l2 = l2a + zz;
+        const float l = std::sqrt((float)l2);
+        float* out = d + 34 + 3 * (2 * k + sgn);
+        if (l < EPS) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; }
+        else { volatile float inv = 1.0f / l; out[0] = v[0] * inv; out[1] = v[1] * inv; out[2] = v[2] * inv; }
+    }
+}
+
 int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     if (!sc) return fail(MI355RT_ERR_INVALID, "scene is null");
     if (sc->sky_rgb || sc->sky_width || sc->sky_height) return fail(MI355RT_ERR_UNSUPPORTED, "HDR skybox (renderer.rs:40-54) is not built yet");
@@ -187,6 +210,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
             volatile float zero = 0.0f;                       // keep the IEEE product (sign of zero, NaN) exactly
             for (int r = 0; r < 3; ++r) d.d[28 + r] = w2o[12 + r] * zero;
             for (int r = 0; r < 3; ++r) d.d[31 + r] = w2o[4 * r + 3] * zero;
+            if (p.kind == MI355RT_PRIM_CUBE) cube_normal_table(d.d);
             if (p.kind == MI355RT_PRIM_MESH) {
                 if (p.mesh >= sc->n_meshes) return fail(MI355RT_ERR_INVALID, "primitive mesh index");
                 d.node_begin = mesh_ranges[p.mesh].first; d.node_end = mesh_ranges[p.mesh].second;

@@ -3,7 +3,7 @@
 // HBM layout (all arrays 16-byte aligned, record sizes multiples of 16 bytes so that the
 // wave-uniform top-level walk lowers to s_load_dwordx4/x8/x16 and the per-lane BVH walk to
 // global_load_dwordx4):
-//   DevPrim[n_prims]   176 B  top-level list in caller order (hittable.rs:45-58), read through the
+//   DevPrim[n_prims]   224 B  top-level list in caller order (hittable.rs:45-58), read through the
 //                             constant address space with a wave-uniform index -> SGPRs
 //   DevMat[n_mats]      64 B  per-lane gather by material index (4 x dwordx4)
 //   DevNode[n_nodes]    32 B  per-mesh BVH in DFS pre-order ("threaded"): the left child of node i
@@ -19,14 +19,15 @@
 
 namespace mi355rt {
 
-struct DevPrim {                 // 44 words = 176 B
+struct DevPrim {                 // 56 words = 224 B
     uint32_t kind, material, node_begin, node_end;   // node range for MI355RT_PRIM_MESH
     // sphere: c[3], r | plane: p1[3], n[3] | quad: base, e0, e1, n, d, inv0, inv1 (15)
     // cube / mesh: w2o[16] (column-major), o2w rows 0..2 of its 4 columns as o2w[12] = {c0.xyz, c1.xyz, c2.xyz, c3.xyz},
-    //              zd[3] = w2o.w_axis.xyz * 0.0f, zn[3] = {w2o[3], w2o[7], w2o[11]} * 0.0f
-    float d[40];
+    //              zd[3] = w2o.w_axis.xyz * 0.0f, zn[3] = {w2o[3], w2o[7], w2o[11]} * 0.0f,
+    //              cube only: d[34..51] = the 6 possible world normals normalized(w2o^T * (+-e_k, 0)), k = x,y,z, + then -
+    float d[52];
 };
-static_assert(sizeof(DevPrim) == 176, "DevPrim must stay 16-byte granular");
+static_assert(sizeof(DevPrim) == 224, "DevPrim must stay 16-byte granular");
 
 struct DevMat {                  // 64 B, same field order as mi355rt_material
     uint32_t kind; float albedo[3];

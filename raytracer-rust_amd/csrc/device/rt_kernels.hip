@@ -288,21 +288,31 @@ DI bool hit_cube(cprim_t pr, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h)
     float t_hit = (t_enter > 0.0f) ? t_enter : t_exit;
     if (t_hit >= t_max || t_hit <= t_min || t_hit < EPS) return false;
     f3 po = ro + rd * t_hit;
-    f3 n = mk(0.f, 0.f, 0.f);
+    // cube.rs:105-134: the object-space normal is +-e_axis, normalize_or_zero() of such a vector is the vector
+    // itself (1/sqrt(1) == 1) unless the chosen coordinate is NaN (then it is zero), and the world normal
+    // normalized(w2o^T * (n, 0)) therefore takes one of 6 values per cube, which the host precomputed with the same
+    // f32 operations (DevPrim.d[34..51], rt_api.cpp cube_normal_table).
     float ax = fabsf(po.x), ay = fabsf(po.y), az = fabsf(po.z);
     const float tol = 1e-4f;
-    if (fabsf(ax - 0.5f) < tol) n.x = glam_signum(po.x);
-    else if (fabsf(ay - 0.5f) < tol) n.y = glam_signum(po.y);
-    else if (fabsf(az - 0.5f) < tol) n.z = glam_signum(po.z);
-    else if (ax > ay && ax > az) n.x = glam_signum(po.x);
-    else if (ay > az) n.y = glam_signum(po.y);
-    else n.z = glam_signum(po.z);
-    {   // Vec3::normalize_or_zero
-        float rcp = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
-        if (isfinite(rcp) && rcp > 0.0f) n = n * rcp; else n = mk(0.f, 0.f, 0.f);
+    uint32_t axis;
+    if (fabsf(ax - 0.5f) < tol) axis = 0u;
+    else if (fabsf(ay - 0.5f) < tol) axis = 1u;
+    else if (fabsf(az - 0.5f) < tol) axis = 2u;
+    else if (ax > ay && ax > az) axis = 0u;
+    else if (ay > az) axis = 1u;
+    else axis = 2u;
+    const float c = (axis == 0u) ? po.x : ((axis == 1u) ? po.y : po.z);
+    f3 nw;
+    if (c != c) {                                         // NaN coordinate: signum -> NaN -> normalize_or_zero -> 0
+        nw = normalized(xform_normal(pr, mk(0.f, 0.f, 0.f)));
+    } else {
+        const uint32_t code = 2u * axis + (__float_as_uint(c) >> 31);     // glam signum: sign bit decides, also for +-0
+        const auto* t = pr->d + 34;
+        nw.x = code == 0u ? t[0] : code == 1u ? t[3] : code == 2u ? t[6] : code == 3u ? t[9] : code == 4u ? t[12] : t[15];
+        nw.y = code == 0u ? t[1] : code == 1u ? t[4] : code == 2u ? t[7] : code == 3u ? t[10] : code == 4u ? t[13] : t[16];
+        nw.z = code == 0u ? t[2] : code == 1u ? t[5] : code == 2u ? t[8] : code == 3u ? t[11] : code == 4u ? t[14] : t[17];
     }
     f3 pw = xform_o2w_point(pr, po);
-    f3 nw = normalized(xform_normal(pr, n));
     if (dot(pw - ro_w, rd_w) < 0.0f) return false;
     float t_world = dot(pw - ro_w, rd_w);
     if (t_world < t_min || t_world > t_max) return false;
