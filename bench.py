@@ -187,13 +187,15 @@ def run_cpu_baseline(abi, scene, W, H, spp, target_seconds):
     import oracle
     oracle.build()
     cores = min(len(os.sched_getaffinity(0)), 16) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # pilot on 1/64 of the rows to pick the sample size
-    pilot = abi.Options.make(rng_mode=abi.RNG_REF, strip_rows=1, n_parts=64, part=0)
-    _, _, c0 = oracle.render(scene, scene.camera, scene.settings, pilot, threads=cores, want_linear=False)
+    # Rows are the unit of parallelism (one row per thread at a time, like rayon's par_chunks_mut), so the sample
+    # is always a multiple of `cores` rows, spread evenly over the image.  Pilot: one row per core.
+    def every(n_rows):
+        n_rows = max(cores, min(H, (n_rows // cores) * cores))
+        return abi.Options.make(rng_mode=abi.RNG_REF, strip_rows=1, n_parts=max(1, -(-H // n_rows)), part=0)   # ceil: never more than n_rows rows
+    _, _, c0 = oracle.render(scene, scene.camera, scene.settings, every(cores), threads=cores, want_linear=False)
     rate = c0.samples / max(c0.seconds, 1e-9)
-    want_rows = max(1, min(H, int(target_seconds * rate / (W * spp))))
-    parts = max(1, H // want_rows)
-    opt = abi.Options.make(rng_mode=abi.RNG_REF, strip_rows=1, n_parts=parts, part=0)
+    opt = every(int(target_seconds * rate / (W * spp)))
+    parts = opt.n_parts
     _, _, c = oracle.render(scene, scene.camera, scene.settings, opt, threads=cores, want_linear=False)
     rows = len(abi.rows_selected(H, opt))
     base = {"value": round(c.samples / c.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",

@@ -81,6 +81,7 @@ struct mi355rt_context {
     int blocks_per_cu[3] = {0, 0, 0}, vgprs[3] = {0, 0, 0}, sgprs = 0;
     uint32_t variant = KERNEL_LOCKSTEP;  // chosen per scene in set_scene
     uint32_t guided_mult = 16;           // run length = (left in shard) / (guided_mult * waves per shard); 16 measured best at 1/8-image launches
+    uint32_t inline_steps = 0;           // 1 when several meshes share the list (many rays miss a mesh's root box: teapot +5..12 %), 0 for a single mesh (semesterbild -10 % otherwise)
     uint32_t trav_min = 24;              // measured optimum 24-32 on semesterbild / teapot (tools/ab_kernel.py)
     bool have_scene = false;
     mi355rt_settings settings{};
@@ -231,8 +232,11 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     if (!tris.empty()) HIP_TRY(hipMemcpy(ctx->tris.p, tris.data(), tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
     ctx->n_prims = sc->n_primitives; ctx->n_mats = sc->n_materials;
     std::memcpy(ctx->miss, sc->miss_color, 12);
-    bool has_mesh = false;
-    for (const auto& pr : prims) has_mesh = has_mesh || pr.kind == MI355RT_PRIM_MESH;
+    uint32_t n_mesh_prims = 0;
+    for (const auto& pr : prims) n_mesh_prims += pr.kind == MI355RT_PRIM_MESH;
+    const bool has_mesh = n_mesh_prims != 0;
+    ctx->inline_steps = n_mesh_prims >= 2 ? 1u : 0u;
+    if (const char* e = std::getenv("MI355RT_INLINE_STEPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->inline_steps = (uint32_t)v; }
     ctx->variant = has_mesh ? KERNEL_STATE_MACHINE : KERNEL_LOCKSTEP;
     if (const char* e = std::getenv("MI355RT_KERNEL")) {            // A/B override (tools/): 0 lockstep, 1 lockstep+mesh, 2 state machine
         const int v = std::atoi(e);
@@ -378,7 +382,7 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         p.width = st.width; p.height = st.height; p.spp = st.samples_per_pixel; p.max_depth = st.max_depth;
         p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
         magic_div(st.samples_per_pixel, p.spp_mul, p.spp_shift); magic_div(st.width, p.width_mul, p.width_shift);
-        p.trav_min = ctx->trav_min;
+        p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;
         ResolveParams r{};
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
         r.spp = st.samples_per_pixel; r.inv_spp = 1.0f / (float)st.samples_per_pixel;     // renderer.rs:85

@@ -76,6 +76,7 @@ struct RenderParams {
     uint32_t seed_lo, seed_hi;
     uint32_t spp_mul, spp_shift, width_mul, width_shift;   // magic pairs for n / spp and n / width (n < 2^31)
     uint32_t trav_min;           // state-machine kernel: run BVH rounds while at least this many lanes are walking
+    uint32_t inline_steps;       // state-machine kernel: box tests taken right at mesh setup (short walks skip the TRAV round trip)
 };
 
 // Which counter-mode kernel serves a scene

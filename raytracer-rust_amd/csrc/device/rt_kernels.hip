@@ -799,9 +799,6 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
 // Register budget per kernel, as waves per SIMD (A/B: tools/ab.py).  The lockstep kernel is VALU-issue bound
 // and gains from 6 waves/SIMD even with a few spills; the state-machine kernel keeps its hot BVH state in
 // registers and loses when capped.
-#ifndef MI355RT_INLINE_STEPS
-#define MI355RT_INLINE_STEPS 1
-#endif
 #ifndef MI355RT_TRAV_BIAS
 #define MI355RT_TRAV_BIAS 2
 #endif
@@ -949,7 +946,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
                                 // take those steps right here so that only long walks pay a TRAV / TOP round trip.
                                 mesh_setup(pr, ps.ro, ps.rd, closest, mt);
 #pragma unroll 1
-                                for (int k = 0; k < MI355RT_INLINE_STEPS; ++k) {
+                                for (uint32_t k = 0; k < P.inline_steps; ++k) {
                                     if (mt.leaf_b != 0u || mt.node >= mt.end) break;
                                     mesh_step(n4, EPS, mt);
                                 }
