@@ -988,28 +988,45 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
 // ===================================================================================================
 // k_resolve -- ordered per-pixel sum, 1/spp, sqrt gamma, pack (renderer.rs:100-120)
 // ===================================================================================================
+// A lane owns a pixel and must add that pixel's samples in order, but one pixel's samples are contiguous in HBM
+// (spp * 16 B apart from the next pixel's).  Each wave therefore moves 64 pixels x 16 samples at a time through
+// LDS: 16 fully coalesced loads (16 lanes x 16 B = 256 contiguous bytes per pixel, 4 pixels per instruction),
+// written to a [pixel][17] float4 image (one slot of padding: lane l reads slot 17*l + k, conflict-free for
+// ds_read_b128), then every lane reads back its own pixel's 16 samples and adds them in sample order.
+// Each wave owns its LDS region, so no workgroup barrier is needed.
+constexpr uint32_t RES_CHUNK = 16, RES_PITCH = 17;
 __global__ void __launch_bounds__(256) k_resolve(const ResolveParams P) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P.band_pixels) return;
-    const float4* __restrict__ r = reinterpret_cast<const float4*>(P.radiance) + (size_t)p * P.spp;
+    __shared__ float4 stage[4][64 * RES_PITCH];                  // 4 waves x 17 408 B
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t p0 = (blockIdx.x * 4u + wave) * 64u;          // first pixel of this wave
+    if (p0 >= P.band_pixels) return;                             // wave-uniform
+    const uint32_t p = p0 + lane;
+    const float4* __restrict__ rad = reinterpret_cast<const float4*>(P.radiance);
+    float4* __restrict__ mine = stage[wave];
+    typedef float v4f __attribute__((ext_vector_type(4)));
     f3 acc = mk(0.f, 0.f, 0.f);
-    uint32_t s = 0;
-    // A lane owns a pixel, so lanes are spp*16 B apart: fetch a whole 128-B line (8 samples) per lane per
-    // step with the 8 loads in flight together, then add in sample order -- otherwise the line is evicted
-    // between its 8 uses (measured 3x over-fetch with one load per step).
-    for (; s + 8 <= P.spp; s += 8) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        v4f v[8];
+    const uint32_t sub_pix = lane >> 4, sub_s = lane & 15u;
+    for (uint32_t c = 0; c < P.spp; c += RES_CHUNK) {
+        const uint32_t s = c + sub_s;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(r + s + k));
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc = acc + mk(v[k].x, v[k].y, v[k].z);
+        for (uint32_t i = 0; i < 16; ++i) {
+            const uint32_t pl = 4u * i + sub_pix;                // pixel within the wave's 64
+            if (p0 + pl < P.band_pixels && s < P.spp) {
+                const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(rad + (size_t)(p0 + pl) * P.spp + s));
+                mine[pl * RES_PITCH + sub_s] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS writes of this wave before its own reads
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n = min(RES_CHUNK, P.spp - c);
+        for (uint32_t k = 0; k < n; ++k) { const float4 v = mine[lane * RES_PITCH + k]; acc = acc + mk(v.x, v.y, v.z); }   // renderer.rs:100
+        __builtin_amdgcn_wave_barrier();                         // reads done before the next chunk overwrites
     }
-    for (; s < P.spp; ++s) { const float4 v = r[s]; acc = acc + mk(v.x, v.y, v.z); }
-    const f3 pixel = acc * P.inv_spp;
+    if (p >= P.band_pixels) return;
+    const f3 pixel = acc * P.inv_spp;                            // renderer.rs:103
     const size_t o = (size_t)P.band_pixel0 + p;
     if (P.out_linear) { P.out_linear[3 * o] = pixel.x; P.out_linear[3 * o + 1] = pixel.y; P.out_linear[3 * o + 2] = pixel.z; }
-    P.out_packed[o] = color_to_u32(sqrt3(pixel));
+    P.out_packed[o] = color_to_u32(sqrt3(pixel));                // renderer.rs:112-120
 }
 
 // ===================================================================================================
@@ -1068,7 +1085,7 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
     return (int)hipGetLastError();
 }
 int launch_resolve(const ResolveParams& p, void* stream) {
-    const uint32_t blocks = (p.band_pixels + 255u) / 256u;
+    const uint32_t blocks = (p.band_pixels + 255u) / 256u;       // 4 waves x 64 pixels per block
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
