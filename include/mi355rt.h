@@ -40,7 +40,7 @@ extern "C" {
 #define MI355RT_ERR_HIP         -3   /* a HIP runtime call or a kernel failed                    */
 #define MI355RT_ERR_OOM         -4   /* host or device allocation failed                         */
 #define MI355RT_ERR_IO          -5   /* file could not be read / parsed (host-side loaders)      */
-#define MI355RT_ERR_UNSUPPORTED -6   /* feature flagged in the ABI but not built (e.g. skybox)   */
+#define MI355RT_ERR_UNSUPPORTED -6   /* feature flagged in the ABI but not built                   */
 
 /* ---- camera: src/camera.rs:4-11 (the fields of `Camera`, computed by Camera::new on the host) */
 typedef struct mi355rt_camera {
@@ -144,7 +144,7 @@ typedef struct mi355rt_scene {
     const uint32_t*          tri_indices; uint32_t n_tri_indices;
     float        miss_color[3];           /* Color::GRAY at HEAD, src/renderer.rs:61             */
     uint32_t     sky_width, sky_height;   /* equirect HDR skybox, src/renderer.rs:40-54; 0 = none */
-    const float* sky_rgb;                 /* sky_width*sky_height*3; not built yet -> UNSUPPORTED */
+    const float* sky_rgb;                 /* sky_width*sky_height*3 f32, row 0 = top; NULL = constant miss_color */
 } mi355rt_scene;
 
 /* ---- options that have no counterpart in the reference ---------------------------------------- */

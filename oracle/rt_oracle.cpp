@@ -391,6 +391,7 @@ bool bvh_intersect_recursive(const BVHNode* node, const Ray& ray, const std::vec
 struct MeshData { std::vector<Tri> tris; std::unique_ptr<BVHNode> bvh; uint32_t max_depth = 0; };
 
 struct Scene {
+    std::vector<float> sky; uint32_t sky_w = 0, sky_h = 0;      // scene.rs:9 skybox_hdr_image
     std::vector<mi355rt_primitive> prims;
     std::vector<mi355rt_material> mats;
     std::vector<MeshData> meshes;
@@ -401,6 +402,11 @@ bool build_scene(const mi355rt_scene* in, Scene& sc) {
     sc.prims.assign(in->primitives, in->primitives + in->n_primitives);
     sc.mats.assign(in->materials, in->materials + in->n_materials);
     sc.miss = {in->miss_color[0], in->miss_color[1], in->miss_color[2]};
+    if (in->sky_rgb) {
+        if (!in->sky_width || !in->sky_height) return false;
+        sc.sky.assign(in->sky_rgb, in->sky_rgb + (size_t)in->sky_width * in->sky_height * 3);
+        sc.sky_w = in->sky_width; sc.sky_h = in->sky_height;
+    }
     sc.meshes.resize(in->n_meshes);
     for (uint32_t m = 0; m < in->n_meshes; ++m) {
         const mi355rt_mesh& md = in->meshes[m];
@@ -765,6 +771,20 @@ inline Col emitted(const mi355rt_material& m) {                                 
     return BLACK;
 }
 
+// renderer.rs:38-63 -- what a missing ray returns
+inline Col miss_colour(const Scene& sc, const Ray& ray_in) {
+    if (sc.sky_w == 0) return sc.miss;                                                // :61
+    V3 dir = normalized(ray_in.direction);                                            // :41
+    float theta = std::acos(dir.y);                                                   // :42
+    float phi = std::atan2(dir.z, dir.x) + PI_F;                                      // :43
+    float u = phi / (2.0f * PI_F);                                                    // :44
+    float v = theta / PI_F;                                                           // :45
+    uint32_t xp = rust_as_u32(std::fmax(u * (float)(sc.sky_w - 1), 0.0f));            // :47
+    uint32_t yp = rust_as_u32(std::fmax(v * (float)(sc.sky_h - 1), 0.0f));            // :48
+    size_t o = 3 * ((size_t)std::min(yp, sc.sky_h - 1) * sc.sky_w + std::min(xp, sc.sky_w - 1));   // :50-53
+    return {sc.sky[o], sc.sky[o + 1], sc.sky[o + 2]};                                 // :54
+}
+
 // ------------------------------------------------------------------------------------------------
 // renderer.rs:19-65 -- trace_ray, exact recursion (tail-first folding)
 // ------------------------------------------------------------------------------------------------
@@ -784,7 +804,7 @@ Col trace_ray_tail(const Ray& ray_in, const Scene& sc, uint32_t depth, S& rng, C
         }
         return emitted_light;
     }
-    return sc.miss;                                                                   // renderer.rs:61 (skybox branch :40-54 not built)
+    return miss_colour(sc, ray_in);                                                   // renderer.rs:38-63
 }
 
 // Same walk, throughput accumulated front-to-back (the GPU's order): L = ((a1*a2)*...*ak) * terminal.
@@ -795,7 +815,7 @@ Col trace_ray_fwd(Ray ray, const Scene& sc, uint32_t max_depth, S& rng, Counters
         if (depth == 0) { ++c.depth_exhausted; return throughput * BLACK; }
         ++c.rays;
         HitRecord h;
-        if (!scene_hit(sc, ray, EPSILON, std::numeric_limits<float>::infinity(), h, c)) return throughput * sc.miss;
+        if (!scene_hit(sc, ray, EPSILON, std::numeric_limits<float>::infinity(), h, c)) return throughput * miss_colour(sc, ray);
         const mi355rt_material& m = sc.mats[h.material];
         Ray scattered; Col atten;
         rng.begin_scatter();
@@ -847,7 +867,6 @@ int oracle_render(const mi355rt_scene* scene_in, const mi355rt_camera* cam, cons
                   oracle_counters* counters_out) {
     Scene sc;
     if (!scene_in || !cam || !st || !build_scene(scene_in, sc)) return MI355RT_ERR_INVALID;
-    if (scene_in->sky_rgb) return MI355RT_ERR_UNSUPPORTED;
     RowSel sel;
     if (!select_rows(*st, opt, sel)) return MI355RT_ERR_INVALID;
     const uint32_t rng_mode = opt ? opt->rng_mode : MI355RT_RNG_CTR;

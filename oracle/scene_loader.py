@@ -241,6 +241,48 @@ def load_wo3(path):
     return _triangles_from_indexed(verts, words[ok])
 
 
+# ---- Radiance .hdr (image::open(..).into_rgb32f(), parser.rs:502-506) ----------------------------------------
+def load_radiance_hdr(path):
+    """Returns float32 [H, W, 3].  RGBE -> f32 as the `image` crate does: c * 2^(e - 136), zero when e == 0."""
+    b = open(path, "rb").read()
+    pos = 0
+
+    def line():
+        nonlocal pos
+        end = b.find(b"\n", pos)
+        end = len(b) if end < 0 else end
+        out = b[pos:end]
+        pos = min(end + 1, len(b))
+        return out
+    if not line().startswith(b"#?"):
+        raise ValueError("not a Radiance HDR file")
+    while pos < len(b) and line() != b"":
+        pass
+    dims = line().split()
+    if len(dims) != 4 or dims[0] != b"-Y" or dims[2] != b"+X":
+        raise ValueError("unsupported HDR orientation")
+    H, W = int(dims[1]), int(dims[3])
+    img = np.zeros((H, W, 4), np.uint8)
+    for y in range(H):
+        if 8 <= W <= 32767 and b[pos:pos + 2] == b"\x02\x02" and ((b[pos + 2] << 8) | b[pos + 3]) == W:
+            pos += 4
+            for c in range(4):
+                x = 0
+                while x < W:
+                    n = b[pos]; pos += 1
+                    if n > 128:
+                        n -= 128
+                        img[y, x:x + n, c] = b[pos]; pos += 1
+                    else:
+                        img[y, x:x + n, c] = np.frombuffer(b, np.uint8, n, pos); pos += n
+                    x += n
+        else:
+            img[y] = np.frombuffer(b, np.uint8, W * 4, pos).reshape(W, 4); pos += W * 4
+    e = img[..., 3].astype(np.float32)
+    scale = np.where(img[..., 3] == 0, F(0.0), np.exp2(e - F(136.0))).astype(F)
+    return (scale[..., None] * img[..., 0:3].astype(F)).astype(F)
+
+
 # ---- tungsten/parser.rs ---------------------------------------------------------------------------
 METAL_TABLE = {  # tungsten/materials.rs:115-152
     "cu": ((0.200, 1.090, 1.420), (3.910, 2.570, 2.300)), "au": ((0.170, 0.350, 1.500), (3.140, 2.300, 1.920)),
@@ -402,6 +444,7 @@ class LoadedScene:
     def __init__(self):
         self.materials, self.primitives, self.meshes = [], [], []
         self.triangles = np.zeros((0, 12), F)
+        self.sky = None                                    # float32 [H, W, 3] or None
         self.c = None
         self.camera = None
         self.settings = None
@@ -424,8 +467,13 @@ class LoadedScene:
         s.nodes, s.n_nodes = None, 0
         s.tri_indices, s.n_tri_indices = None, 0
         s.miss_color[:] = [0.5, 0.5, 0.5]                  # Color::GRAY, renderer.rs:61
-        s.sky_width = s.sky_height = 0
-        s.sky_rgb = None
+        if self.sky is not None:
+            self._sky_np = np.ascontiguousarray(self.sky, dtype=F)
+            s.sky_height, s.sky_width = self._sky_np.shape[0], self._sky_np.shape[1]
+            s.sky_rgb = self._sky_np.ctypes.data_as(C.POINTER(C.c_float))
+        else:
+            s.sky_width = s.sky_height = 0
+            s.sky_rgb = None
         self.c = s
         return self
 
@@ -464,6 +512,13 @@ def load_scene(json_path, width=0, height=0, spp=0, max_depth=0, skip_unknown_pr
     aspect = F(F(w) / F(h)) if aspect is None else f32(aspect)       # parser.rs:294-297
     tr = cam["transform"]
     out.camera = camera_new(_vec3cfg(tr["position"]), _vec3cfg(tr["look_at"]), _vec3cfg(tr["up"]), f32(cam["fov"]), aspect)
+
+    sky = cfg.get("sky")                                    # parser.rs:497-521: only an .hdr texture is ever sampled
+    if sky and sky.get("texture") and sky["texture"].endswith(".hdr"):
+        try:
+            out.sky = load_radiance_hdr(os.path.join(scene_dir, sky["texture"]))
+        except (OSError, ValueError):
+            out.sky = None
 
     bsdf_index = {}
     for b in cfg.get("bsdfs") or []:

@@ -91,6 +91,7 @@ struct mi355rt_context {
     DevBuf<DevPrim> prims; DevBuf<DevMat> mats; DevBuf<DevNode> nodes; DevBuf<DevTri> tris;
     DevBuf<uint32_t> rows; DevBuf<float> radiance; DevBuf<uint32_t> counters; DevBuf<unsigned long long> stats;
     DevBuf<float> fold_stack;
+    DevBuf<float> sky; uint32_t sky_w = 0, sky_h = 0;      // equirect HDR skybox (renderer.rs:40-54); sky_w == 0: none
     DevBuf<unsigned long long> wave_times; uint32_t wave_times_n = 0;   // diagnostics (MI355RT_WAVE_TIMES=1)
     std::vector<uint32_t> rows_host;     // source of the async row-table upload; must outlive the copy
     bool rows_valid = false;             // ctx->rows already holds rows_host (same selection as the last call)
@@ -184,7 +185,11 @@ void cube_normal_table(float* d) {
 
 int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     if (!sc) return fail(MI355RT_ERR_INVALID, "scene is null");
-    if (sc->sky_rgb || sc->sky_width || sc->sky_height) return fail(MI355RT_ERR_UNSUPPORTED, "HDR skybox (renderer.rs:40-54) is not built yet");
+    const bool has_sky = sc->sky_rgb != nullptr;
+    if (has_sky != (sc->sky_width != 0 && sc->sky_height != 0) || (!has_sky && (sc->sky_width || sc->sky_height)))
+        return fail(MI355RT_ERR_INVALID, "sky_rgb / sky_width / sky_height are inconsistent");
+    if (has_sky && ((uint64_t)sc->sky_width * sc->sky_height > (1ull << 28) || sc->sky_width >= (1u << 24) || sc->sky_height >= (1u << 24)))
+        return fail(MI355RT_ERR_INVALID, "skybox too large");
     if (sc->n_primitives && !sc->primitives) return fail(MI355RT_ERR_INVALID, "primitives is null");
     if (sc->n_materials && !sc->materials) return fail(MI355RT_ERR_INVALID, "materials is null");
     for (uint32_t i = 0; i < sc->n_materials; ++i)
@@ -232,6 +237,13 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     if (!tris.empty()) HIP_TRY(hipMemcpy(ctx->tris.p, tris.data(), tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
     ctx->n_prims = sc->n_primitives; ctx->n_mats = sc->n_materials;
     std::memcpy(ctx->miss, sc->miss_color, 12);
+    ctx->sky_w = ctx->sky_h = 0;
+    if (has_sky) {
+        const size_t nf = (size_t)sc->sky_width * sc->sky_height * 3;
+        if ((rc = ctx->sky.ensure(nf))) return rc;
+        HIP_TRY(hipMemcpy(ctx->sky.p, sc->sky_rgb, nf * sizeof(float), hipMemcpyHostToDevice));
+        ctx->sky_w = sc->sky_width; ctx->sky_h = sc->sky_height;
+    }
     uint32_t n_mesh_prims = 0;
     for (const auto& pr : prims) n_mesh_prims += pr.kind == MI355RT_PRIM_MESH;
     const bool has_mesh = n_mesh_prims != 0;
@@ -290,7 +302,7 @@ void mi355rt_context_destroy(mi355rt_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     ctx->prims.release(); ctx->mats.release(); ctx->nodes.release(); ctx->tris.release(); ctx->rows.release();
-    ctx->radiance.release(); ctx->counters.release(); ctx->stats.release(); ctx->fold_stack.release(); ctx->wave_times.release();
+    ctx->radiance.release(); ctx->counters.release(); ctx->stats.release(); ctx->fold_stack.release(); ctx->wave_times.release(); ctx->sky.release();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->pool) if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -346,6 +358,7 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         if ((rc = ctx->fold_stack.ensure((size_t)n_rows * std::max(st.max_depth, 1u) * 3))) return rc;
         RefParams rp{};
         rp.prims = ctx->prims.p; rp.mats = ctx->mats.p; rp.nodes = ctx->nodes.p; rp.tris = ctx->tris.p; rp.rows = ctx->rows.p;
+        rp.sky = ctx->sky_w ? ctx->sky.p : nullptr; rp.sky_w = ctx->sky_w; rp.sky_h = ctx->sky_h;
         rp.out_packed = (uint32_t*)d_out_packed; rp.out_linear = (float*)d_out_linear; rp.fold_stack = ctx->fold_stack.p; rp.stats = ctx->stats.p;
         rp.n_prims = ctx->n_prims; rp.n_mats = ctx->n_mats; rp.n_rows = n_rows;
         std::memcpy(rp.miss, ctx->miss, 12); rp.cam = ctx->cam;
@@ -376,6 +389,7 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
 
         RenderParams p{};
         p.prims = ctx->prims.p; p.mats = ctx->mats.p; p.nodes = ctx->nodes.p; p.tris = ctx->tris.p; p.rows = ctx->rows.p;
+        p.sky = ctx->sky_w ? ctx->sky.p : nullptr; p.sky_w = ctx->sky_w; p.sky_h = ctx->sky_h;
         p.radiance = ctx->radiance.p; p.stats = ctx->stats.p;
         p.n_prims = ctx->n_prims; p.n_mats = ctx->n_mats;
         std::memcpy(p.miss, ctx->miss, 12); p.cam = ctx->cam;

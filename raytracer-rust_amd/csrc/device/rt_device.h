@@ -12,6 +12,7 @@
 //   DevTri[n_tris]      48 B  triangles re-ordered into leaf order, stored as v0, e1=v1-v0, e2=v2-v0,
 //                             normal (the same f32 subtractions bvh.rs:95-96 performs per test)
 //   rows[n_rows]         4 B  local output row -> absolute image row y (the RNG key)
+//   sky[h*w*3]           4 B  optional equirect HDR skybox, per-lane nearest-texel gather on miss
 //   radiance[band]      16 B  one float4 per path (sample-major inside a pixel), written once by
 //                             the path tracer and read once by the resolve kernel
 #pragma once
@@ -61,6 +62,7 @@ constexpr uint32_t WORK_SHARD_STRIDE = 32;     // u32 words between counters: on
 struct RenderParams {
     const DevPrim* prims; const DevMat* mats; const DevNode* nodes; const DevTri* tris;
     const uint32_t* rows;        // local row -> absolute y
+    const float* sky; uint32_t sky_w, sky_h;   // equirect HDR skybox (RGB f32), null = constant miss colour
     float* radiance;             // float4 per band sample
     uint32_t* batch_counter;     // WORK_SHARDS counters (WORK_SHARD_STRIDE words apart): next unclaimed sample of each shard; zeroed per band
     unsigned long long* stats;   // [0] = paths started, [1] = rays traced
@@ -97,6 +99,7 @@ struct ResolveParams {
 struct RefParams {               // MI355RT_RNG_REF: one lane per selected row
     const DevPrim* prims; const DevMat* mats; const DevNode* nodes; const DevTri* tris;
     const uint32_t* rows;
+    const float* sky; uint32_t sky_w, sky_h;
     uint32_t* out_packed; float* out_linear;
     float* fold_stack;           // n_rows * max_depth * 3 floats (attenuation stack for tail-first folding)
     unsigned long long* stats;

@@ -604,6 +604,21 @@ DI bool surface_scatter(const DevMat* __restrict__ mats, const float4 q0, const 
     return true;
 }
 
+// renderer.rs:38-63: the colour a missing ray returns -- equirectangular HDR lookup (nearest texel) when a skybox
+// is loaded, Color::GRAY (passed in as `miss`) otherwise.
+DI f3 miss_colour(const float* __restrict__ sky, uint32_t sky_w, uint32_t sky_h, const float (&miss)[3], f3 rd) {
+    if (sky == nullptr) return mk(miss[0], miss[1], miss[2]);                      // renderer.rs:61
+    const f3 dir = normalized(rd);                                                  // :41
+    const float theta = acosf(dir.y);                                               // :42
+    const float phi = atan2f(dir.z, dir.x) + PI_F;                                  // :43
+    const float u = phi / (2.0f * PI_F);                                            // :44
+    const float v = theta / PI_F;                                                   // :45
+    const uint32_t xp = as_u32_sat(fmaxf(u * (float)(sky_w - 1u), 0.0f));           // :47  (f32::max ignores NaN, `as u32` saturates)
+    const uint32_t yp = as_u32_sat(fmaxf(v * (float)(sky_h - 1u), 0.0f));           // :48
+    const size_t o = 3 * ((size_t)min(yp, sky_h - 1u) * sky_w + min(xp, sky_w - 1u));   // :50-53
+    return mk(sky[o], sky[o + 1], sky[o + 2]);
+}
+
 // camera.rs:33-42 + ray.rs:12-17
 DI void camera_ray(const DevCamera& cam, float u, float v, f3& ro, f3& rd) {
     float ndc_x = 2.0f * u - 1.0f;
@@ -748,7 +763,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         f3 term = mk(0.f, 0.f, 0.f); bool fin = false;
-        if (!hit) { term = mk(P.miss[0], P.miss[1], P.miss[2]); fin = true; }            // renderer.rs:61
+        if (!hit) { term = miss_colour(P.sky, P.sky_w, P.sky_h, P.miss, ps.rd); fin = true; }   // renderer.rs:38-63
         else {
             q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
             const uint32_t kind = __float_as_uint(q0.x);
@@ -1054,7 +1069,7 @@ __global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
                 if (depth == P.max_depth) break;
                 ++n_rays;
                 Hit h;
-                if (!hit_scene<true>(prims, P.n_prims, P.nodes, P.tris, ro, rd, h)) { term = mk(P.miss[0], P.miss[1], P.miss[2]); break; }
+                if (!hit_scene<true>(prims, P.n_prims, P.nodes, P.tris, ro, rd, h)) { term = miss_colour(P.sky, P.sky_w, P.sky_h, P.miss, rd); break; }
                 f3 no, nd, atten, emitted;
                 const float4 q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
                 if (!surface_scatter(P.mats, q0, h, rd, rng, no, nd, atten, emitted)) { term = emitted; break; }

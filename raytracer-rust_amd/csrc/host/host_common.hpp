@@ -14,4 +14,7 @@ int set_error(int code, const std::string& msg);      // records the thread-loca
 int bvh_build(const mi355rt_triangle* tris, uint32_t n, std::vector<mi355rt_bvh_node>& nodes, std::vector<uint32_t>& indices,
               uint32_t& max_depth);
 
+// hdr_io.cpp
+int load_radiance_hdr(const std::string& path, uint32_t& width, uint32_t& height, std::vector<float>& rgb);
+
 }  // namespace mi355rt_host

@@ -28,6 +28,7 @@ struct mi355rt_loaded_scene {
     std::vector<mi355rt_triangle> tris;
     std::vector<mi355rt_bvh_node> nodes;
     std::vector<uint32_t> indices;
+    std::vector<float> sky; uint32_t sky_w = 0, sky_h = 0;     // scene.skybox_hdr_image (parser.rs:497-509)
     mi355rt_scene scene{};
     mi355rt_camera camera{};
     mi355rt_settings settings{};
@@ -246,6 +247,19 @@ void load_impl(const std::string& json_path, const mi355rt_load_overrides* ov, m
         return add_material(make_mat(MI355RT_MAT_LAMBERT_SOLID, 1.f, 0.f, 1.f));  // Color::MAGENTA fallback (parser.rs:541-543)
     };
 
+    // `sky` (parser.rs:497-521): only a texture ending in ".hdr" feeds trace_ray (renderer.rs:40); an LDR image is
+    // loaded into scene.skybox_image, which nothing reads.  A load error keeps the default background.
+    if (const JsonValue* sky = cfg.opt("sky")) {
+        if (!sky->is_object()) bad("sky must be a map");
+        if (const JsonValue* tex = sky->opt("texture")) {
+            if (!tex->is_string()) bad("sky.texture must be a string");
+            const std::string& rel = tex->str;
+            if (rel.size() >= 4 && rel.compare(rel.size() - 4, 4, ".hdr") == 0) {
+                if (load_radiance_hdr(scene_dir + "/" + rel, out.sky_w, out.sky_h, out.sky) != MI355RT_OK) { out.sky.clear(); out.sky_w = out.sky_h = 0; }
+            }
+        }
+    }
+
     const JsonValue* prims = cfg.get("primitives");
     if (!prims || !prims->is_array()) bad("missing field `primitives`");
     for (const JsonValue& p : prims->arr) {
@@ -339,7 +353,7 @@ void load_impl(const std::string& json_path, const mi355rt_load_overrides* ov, m
     s.nodes = out.nodes.data(); s.n_nodes = (uint32_t)out.nodes.size();
     s.tri_indices = out.indices.data(); s.n_tri_indices = (uint32_t)out.indices.size();
     s.miss_color[0] = s.miss_color[1] = s.miss_color[2] = 0.5f;                  // Color::GRAY, renderer.rs:61
-    s.sky_width = s.sky_height = 0; s.sky_rgb = nullptr;                         // `sky` key: no shipped scene has one (renderer.rs:40-54)
+    s.sky_width = out.sky_w; s.sky_height = out.sky_h; s.sky_rgb = out.sky.empty() ? nullptr : out.sky.data();   // renderer.rs:40-54
 }
 
 }  // namespace

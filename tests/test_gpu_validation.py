@@ -73,7 +73,8 @@ def test_settings_and_options_are_validated(native, oracle_mod, abi):
     rc, msg = _render_rc(device, abi, sc, cam, st, o)
     assert rc == abi.ERR_INVALID and "workspace" in msg
     sky = abi.Scene(); C.memmove(C.byref(sky), C.byref(sc.c), C.sizeof(abi.Scene)); sky.sky_width = 4; sky.sky_height = 2
-    assert _render_rc(device, abi, sky, cam, st)[0] == abi.ERR_UNSUPPORTED
+    rc, msg = _render_rc(device, abi, sky, cam, st)              # dimensions without pixels
+    assert rc == abi.ERR_INVALID and "sky" in msg
     # max_depth 0: every path is BLACK without tracing (renderer.rs:20-22)
     st0 = abi.Settings(8, 6, 2, 0)
     packed, lin, stats = device.render(sc, cam, st0, abi.Options.make())
