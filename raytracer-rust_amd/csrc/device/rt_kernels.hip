@@ -200,7 +200,7 @@ DI void set_face(Hit& h, f3 rd, f3 outward, uint32_t material) {                
     h.mat_ff = material | (front ? 0x80000000u : 0u);
 }
 
-// objects/sphere.rs:15-53
+// objects/sphere.rs:15-53 (rejections folded into one predicate; sqrt of a negative discriminant is discarded)
 DI bool hit_sphere(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
     f3 center = mk(pr->d[0], pr->d[1], pr->d[2]); float radius = pr->d[3];
     f3 oc = ro - center;
@@ -208,13 +208,11 @@ DI bool hit_sphere(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
     float half_b = dot(oc, rd);
     float c = dot(oc, oc) - radius * radius;
     float disc = half_b * half_b - a * c;
-    if (disc < 0.0f) return false;
     float sqrtd = sqrtf(disc);
-    float root = (-half_b - sqrtd) / a;
-    if (root <= t_min || root >= t_max) {
-        root = (-half_b + sqrtd) / a;
-        if (root <= t_min || root >= t_max) return false;
-    }
+    float r0 = (-half_b - sqrtd) / a, r1 = (-half_b + sqrtd) / a;
+    const bool ok0 = !(r0 <= t_min || r0 >= t_max), ok1 = !(r1 <= t_min || r1 >= t_max);
+    if (disc < 0.0f || !(ok0 || ok1)) return false;
+    const float root = ok0 ? r0 : r1;
     h.t = root;
     h.p = ro + rd * root;
     set_face(h, rd, divf(h.p - center, radius), pr->material);
@@ -225,21 +223,22 @@ DI bool hit_sphere(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
 DI bool hit_plane(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
     f3 p1 = mk(pr->d[0], pr->d[1], pr->d[2]), n = mk(pr->d[3], pr->d[4], pr->d[5]);
     float denom = dot(n, rd);
-    if (fabsf(denom) < EPS) return false;
     float t = dot(n, p1 - ro) / denom;
-    if (t <= t_min || t >= t_max) return false;
+    if ((fabsf(denom) < EPS) || (t <= t_min || t >= t_max)) return false;
     h.t = t; h.p = ro + rd * t;
     set_face(h, rd, n, pr->material);
     return true;
 }
 
-// tungsten/objects/quad.rs:83-132
+// tungsten/objects/quad.rs:83-132.  The two cheap rejections (parallel ray, t out of range) are folded into one
+// predicate so the wave takes a single branch into the parallelogram test; the arithmetic is unchanged (the
+// division also runs for |denom| < EPS lanes, whose result is discarded).
 DI bool hit_quad(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
     f3 n = mk(pr->d[9], pr->d[10], pr->d[11]);
     float denom = dot(n, rd);
-    if (fabsf(denom) < EPS) return false;
     float t = (pr->d[12] - dot(n, ro)) / denom;
-    if (t <= t_min || t >= t_max) return false;
+    const bool candidate = !(fabsf(denom) < EPS) && !(t <= t_min || t >= t_max);
+    if (!candidate) return false;
     f3 hit_pos = ro + rd * t;
     f3 v = hit_pos - mk(pr->d[0], pr->d[1], pr->d[2]);
     float l0 = dot(v, mk(pr->d[3], pr->d[4], pr->d[5])) * pr->d[13];
@@ -247,7 +246,9 @@ DI bool hit_quad(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
     const float lo = -EPS, hi = 1.0f + EPS;
     if (!((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi))) return false;
     h.t = t; h.p = hit_pos;
-    set_face(h, rd, n, pr->material);
+    const bool front = denom < 0.0f;                      // dot(ray.direction, normal) is the same sum of the same products
+    h.n = front ? n : -n;
+    h.mat_ff = pr->material | (front ? 0x80000000u : 0u);
     return true;
 }
 
@@ -284,9 +285,9 @@ DI bool hit_cube(cprim_t pr, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h)
     float t1z = (-0.5f - ro.z) * iz, t2z = (0.5f - ro.z) * iz;
     float t_enter = fmaxf(fminf(t1x, t2x), fmaxf(fminf(t1y, t2y), fminf(t1z, t2z)));
     float t_exit = fminf(fmaxf(t1x, t2x), fminf(fmaxf(t1y, t2y), fmaxf(t1z, t2z)));
-    if (t_exit < t_enter || t_exit <= 0.0f) return false;
-    float t_hit = (t_enter > 0.0f) ? t_enter : t_exit;
-    if (t_hit >= t_max || t_hit <= t_min || t_hit < EPS) return false;
+    const float t_hit = (t_enter > 0.0f) ? t_enter : t_exit;
+    const bool candidate = !(t_exit < t_enter || t_exit <= 0.0f) && !(t_hit >= t_max || t_hit <= t_min || t_hit < EPS);   // cube.rs:90-103, one branch
+    if (!candidate) return false;
     f3 po = ro + rd * t_hit;
     // cube.rs:105-134: the object-space normal is +-e_axis, normalize_or_zero() of such a vector is the vector
     // itself (1/sqrt(1) == 1) unless the chosen coordinate is NaN (then it is zero), and the world normal
@@ -366,16 +367,15 @@ DI void mesh_leaf(const float4* __restrict__ t4, float t_min, MeshTrav& m) {
         const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
         f3 hh = cross(m.rd, e2);
         float aa = dot(e1, hh);
-        if (fabsf(aa) < EPS) continue;
         float f = 1.0f / aa;
         f3 s = m.ro - v0;
         float u = f * dot(s, hh);
-        if (!(u >= 0.0f && u <= 1.0f)) continue;
         f3 q = cross(s, e1);
         float v = f * dot(m.rd, q);
-        if (v < 0.0f || u + v > 1.0f) continue;
         float t = f * dot(e2, q);
-        if (t > t_min && t < m.best_t) { m.best_t = t; m.best_tri = m.leaf_a + k; }
+        // bvh.rs:99-116, the four `continue`s as one predicate (same values, one branch)
+        const bool hit = !(fabsf(aa) < EPS) && (u >= 0.0f && u <= 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > t_min && t < m.best_t);
+        if (hit) { m.best_t = t; m.best_tri = m.leaf_a + k; }
     }
     m.leaf_b = 0; m.node = m.node + 1;
 }
