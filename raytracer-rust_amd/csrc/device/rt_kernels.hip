@@ -295,13 +295,8 @@ DI bool hit_cube(cprim_t pr, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h)
     // f32 operations (DevPrim.d[34..51], rt_api.cpp cube_normal_table).
     float ax = fabsf(po.x), ay = fabsf(po.y), az = fabsf(po.z);
     const float tol = 1e-4f;
-    uint32_t axis;
-    if (fabsf(ax - 0.5f) < tol) axis = 0u;
-    else if (fabsf(ay - 0.5f) < tol) axis = 1u;
-    else if (fabsf(az - 0.5f) < tol) axis = 2u;
-    else if (ax > ay && ax > az) axis = 0u;
-    else if (ay > az) axis = 1u;
-    else axis = 2u;
+    const uint32_t axis = (fabsf(ax - 0.5f) < tol) ? 0u : (fabsf(ay - 0.5f) < tol) ? 1u : (fabsf(az - 0.5f) < tol) ? 2u
+                        : (ax > ay && ax > az) ? 0u : (ay > az) ? 1u : 2u;                    // cube.rs:112-133 as selects
     const float c = (axis == 0u) ? po.x : ((axis == 1u) ? po.y : po.z);
     f3 nw;
     if (c != c) {                                         // NaN coordinate: signum -> NaN -> normalize_or_zero -> 0
@@ -314,9 +309,8 @@ DI bool hit_cube(cprim_t pr, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h)
         nw.z = code == 0u ? t[2] : code == 1u ? t[5] : code == 2u ? t[8] : code == 3u ? t[11] : code == 4u ? t[14] : t[17];
     }
     f3 pw = xform_o2w_point(pr, po);
-    if (dot(pw - ro_w, rd_w) < 0.0f) return false;
-    float t_world = dot(pw - ro_w, rd_w);
-    if (t_world < t_min || t_world > t_max) return false;
+    const float t_world = dot(pw - ro_w, rd_w);                                             // cube.rs:145-153: the same dot product twice
+    if ((t_world < 0.0f) || (t_world < t_min || t_world > t_max)) return false;
     h.t = t_world; h.p = pw;
     set_face(h, rd_w, nw, pr->material);
     return true;
