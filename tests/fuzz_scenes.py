@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 
-def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60):
+def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60, only_kinds=None):
     from oracle import scene_loader as L
     rng = np.random.default_rng(seed)
     F = np.float32
@@ -32,7 +32,10 @@ def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60):
         return L.mat4_from_scale_rotation_translation([F(v) for v in rng.uniform(0.4, 2.0, 3)], q, [F(v) for v in rng.uniform(-3, 3, 3)])
 
     prims, tri_chunks, meshes = [], [], []
-    order = [abi.PRIM_SPHERE, abi.PRIM_PLANE, abi.PRIM_QUAD, abi.PRIM_CUBE, abi.PRIM_MESH] + list(rng.integers(0, 5, n_prims - 5))
+    if only_kinds is not None:
+        order = [only_kinds[i % len(only_kinds)] for i in range(n_prims)]
+    else:
+        order = [abi.PRIM_SPHERE, abi.PRIM_PLANE, abi.PRIM_QUAD, abi.PRIM_CUBE, abi.PRIM_MESH] + list(rng.integers(0, 5, n_prims - 5))
     n_tri = 0
     for kind in order:
         p = abi.Primitive(); p.kind = int(kind); p.material = int(kinds[rng.integers(0, len(kinds))])
@@ -47,9 +50,10 @@ def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60):
             m = matrix(); p.data[0:16] = [float(v) for v in m]; p.data[16:32] = [float(v) for v in L.mat4_inverse(m)]
         else:
             m = matrix(); p.data[0:16] = [float(v) for v in m]; p.data[16:32] = [float(v) for v in L.mat4_inverse(m)]
-            v = rng.uniform(-1, 1, size=(mesh_tris, 3, 3)).astype(F)
-            v[: mesh_tris // 4, :, 2] = F(0.25)                                   # a coplanar patch: zero-thickness leaf boxes (App. B-1)
-            idx = np.arange(mesh_tris * 3).reshape(mesh_tris, 3)
+            nt = mesh_tris if mesh_tris > 0 else int(rng.integers(1, 4))          # mesh_tris <= 0: tiny meshes of 1..3 triangles
+            v = rng.uniform(-1, 1, size=(nt, 3, 3)).astype(F)
+            v[: nt // 4, :, 2] = F(0.25)                                   # a coplanar patch: zero-thickness leaf boxes (App. B-1)
+            idx = np.arange(nt * 3).reshape(nt, 3)
             tris = L._triangles_from_indexed(v.reshape(-1, 3), idx)
             mesh = abi.Mesh(); mesh.first_triangle, mesh.triangle_count = n_tri, len(tris)
             n_tri += len(tris); tri_chunks.append(tris); meshes.append(mesh); p.mesh = len(meshes) - 1

@@ -50,3 +50,22 @@ def test_hip_matches_oracle_on_fuzz_scenes_with_rough_conductors(seed, native, o
     l2 = np.sqrt(((gl.astype(np.float64) - ol) ** 2).sum(-1))
     assert (l2 <= 1e-3).mean() >= 0.995 and (gp == op).mean() >= 0.99
     assert abs(stats.rays - cnt.rays) <= 0.001 * cnt.rays
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,kw", [
+    ("meshes only", dict(n_prims=6, only_kinds=[4], mesh_tris=200)),
+    ("tiny meshes", dict(n_prims=9, only_kinds=[4, 2, 4], mesh_tris=0)),
+    ("mesh first and last", dict(n_prims=7, only_kinds=[4, 0, 3, 2, 1, 3, 4], mesh_tris=40)),
+    ("long list", dict(n_prims=70, mesh_tris=25)),
+])
+def test_state_machine_corner_shapes(label, kw, native, oracle_mod, abi):
+    host, device = native
+    sc = random_scene(abi, host, 21, exact_only=True, **kw)
+    st = abi.Settings(48, 36, 5, 7)
+    for mode in (0, 1):
+        opt = abi.Options.make(rng_mode=mode)
+        gp, gl, stats = device.render(sc, sc.camera, st, opt)
+        op, ol, cnt = oracle_mod.render(sc, sc.camera, st, opt)
+        assert stats.rays == cnt.rays, label
+        assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op), label
