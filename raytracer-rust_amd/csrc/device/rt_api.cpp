@@ -372,7 +372,7 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
             float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
             render_ms = total_ms = ms;
         }
-        n_bands = 1; grid_blocks = (n_rows + 63) / 64; block_threads = 64;
+        n_bands = 1; grid_blocks = n_rows; block_threads = 64;
     } else {
         // ---- band plan: the radiance workspace holds band_pixels * spp float4 ----
         const uint64_t spp = st.samples_per_pixel;

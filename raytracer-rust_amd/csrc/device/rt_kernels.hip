@@ -1043,7 +1043,11 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveParams P) {
 // ===================================================================================================
 __global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
     cprim_t prims = (cprim_t)(P.prims);
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    // One row per WAVE, carried by lane 0: rows consume their streams at data-dependent rates, so 64 rows in one wave
+    // would run in lockstep through 64 different control flows; one active lane per wave has no divergence and the
+    // rows spread over all CUs (the chip is otherwise idle in this validation mode).
+    if ((threadIdx.x & 63u) != 0u) return;
+    const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (j >= P.n_rows) return;
     const uint32_t y = P.rows[j];
     RngRef rng;
@@ -1099,8 +1103,7 @@ int launch_resolve(const ResolveParams& p, void* stream) {
     return (int)hipGetLastError();
 }
 int launch_render_ref(const RefParams& p, void* stream) {
-    const uint32_t blocks = (p.n_rows + 63u) / 64u;
-    hipLaunchKernelGGL(k_render_ref, dim3(blocks), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_render_ref, dim3(p.n_rows), dim3(64), 0, (hipStream_t)stream, p);      // one wave per row
     return (int)hipGetLastError();
 }
 int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs) {
