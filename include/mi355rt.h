@@ -166,7 +166,8 @@ typedef struct mi355rt_options {
     uint32_t row_begin, row_end;
     uint32_t strip_rows, n_parts, part;
     uint32_t _pad;
-    uint64_t workspace_bytes; /* cap for the per-sample radiance workspace in HBM; 0 = default     */
+    uint64_t workspace_bytes; /* cap for the per-sample radiance workspace in HBM; 0 = default (32 GiB,
+                                 of which only width*rows*spp*16 bytes are allocated)             */
 } mi355rt_options;
 
 typedef struct mi355rt_stats {

@@ -377,7 +377,7 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         // ---- band plan: the radiance workspace holds band_pixels * spp float4 ----
         const uint64_t spp = st.samples_per_pixel;
         const uint64_t total_pixels = (uint64_t)n_rows * st.width;
-        uint64_t ws_cap = (opt && opt->workspace_bytes) ? opt->workspace_bytes : (4ull << 30);
+        uint64_t ws_cap = (opt && opt->workspace_bytes) ? opt->workspace_bytes : (32ull << 30);   // 288 GB of HBM: default = the 2^31-sample band limit; only what a band needs is allocated
         uint64_t max_samples = std::min<uint64_t>(ws_cap / 16, (1ull << 31) - 2 * BATCH_MAX);
         if (max_samples < spp) return fail(MI355RT_ERR_INVALID, "workspace_bytes too small for one pixel (needs spp * 16 bytes)");
         const uint64_t band_pixels_max = std::min<uint64_t>(max_samples / spp, total_pixels);
