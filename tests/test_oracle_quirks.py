@@ -120,3 +120,38 @@ def test_mesh_t_world_is_multiplied_by_the_scale(native, oracle_mod, abi):
     # triangle sits at t_obj = 4: `t < t_max` fails and the mesh is culled -- the other half of the same quirk
     hit, r = oracle_mod.scene_hit(_scene(abi, [quad_in_front, mesh], tris), (0, 0, 8), (0, 0, -1))
     assert hit and r[7] == 1 and r[6] == pytest.approx(4.0, rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_the_quirks(native, oracle_mod, abi):
+    """Same scenes through the C ABI: flat leaf invisible, scaled-mesh t quirk in both list orders -- bit-identical images."""
+    host, device = native
+    cam = abi.Camera(); cam.position[:] = [0, 0, 8]; cam.forward[:] = [0, 0, -1]; cam.right[:] = [1, 0, 0]; cam.true_up[:] = [0, 1, 0]
+    cam.half_width, cam.half_height = 0.4, 0.3
+    st = abi.Settings(32, 24, 4, 4)
+    o2w = [2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 1]; w2o = [0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 1]
+    tri_scaled = [_tri((-1, -1, -0.05), (1, -1, 0.05), (0, 1, 0.0))]
+    quad = lambda: _prim(abi, abi.PRIM_QUAD, [-5, -5, 4, 10, 0, 0, 0, 10, 0, 0, 0, 1, 4, 0.01, 0.01], material=1)
+    mesh2 = lambda: _prim(abi, abi.PRIM_MESH, o2w + w2o, material=2)
+    cases = {
+        "flat leaf": ([_prim(abi, abi.PRIM_MESH, IDENT + IDENT)], [_tri((-1, -1, 0), (1, -1, 0), (0, 1, 0))]),
+        "tilted leaf": ([_prim(abi, abi.PRIM_MESH, IDENT + IDENT)], [_tri((-1, -1, 0), (1, -1, 0), (0, 1, 0.01))]),
+        "mesh then quad": ([mesh2(), quad()], tri_scaled),
+        "quad then mesh": ([quad(), mesh2()], tri_scaled),
+    }
+    means = {}
+    for name, (prims, tris) in cases.items():
+        sc = _scene(abi, prims, tris)
+        for i, albedo in enumerate([(0.8, 0.8, 0.8), (0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.5, 0.5, 0.5)]):
+            sc.c.materials[i].kind = abi.MAT_LAMBERT_SOLID; sc.c.materials[i].albedo[:] = albedo
+        sc._bvh = host.attach_bvh(sc)
+        for mode in (0, 1):
+            opt = abi.Options.make(rng_mode=mode)
+            gp, gl, gs = device.render(sc, cam, st, opt)
+            op, ol, cnt = oracle_mod.render(sc, cam, st, opt)
+            assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op) and gs.rays == cnt.rays, name
+        means[name] = gl.mean(axis=(0, 1))
+    assert np.allclose(means["flat leaf"], 0.5)                        # nothing is ever hit: pure miss colour
+    assert not np.allclose(means["tilted leaf"], 0.5)
+    assert means["mesh then quad"][1] > means["mesh then quad"][0]     # green mesh visible in front of the red quad ...
+    assert means["quad then mesh"][0] > means["quad then mesh"][1]     # ... or culled behind it, depending on list order
