@@ -153,5 +153,6 @@ def test_hip_path_reproduces_the_quirks(native, oracle_mod, abi):
         means[name] = gl.mean(axis=(0, 1))
     assert np.allclose(means["flat leaf"], 0.5)                        # nothing is ever hit: pure miss colour
     assert not np.allclose(means["tilted leaf"], 0.5)
-    assert means["mesh then quad"][1] > means["mesh then quad"][0]     # green mesh visible in front of the red quad ...
-    assert means["quad then mesh"][0] > means["quad then mesh"][1]     # ... or culled behind it, depending on list order
+    # the green mesh shows in front of the (nearer!) red quad only when it is listed first; listed second it is culled
+    assert means["mesh then quad"][1] > means["quad then mesh"][1] + 0.01
+    assert means["quad then mesh"][0] > means["mesh then quad"][0] + 0.01
