@@ -78,7 +78,7 @@ template <class T> struct DevBuf {
 struct mi355rt_context {
     int device = 0;
     int cu_count = 0;
-    int blocks_per_cu[3] = {0, 0, 0}, vgprs[3] = {0, 0, 0}, sgprs = 0;
+    int blocks_per_cu[KERNEL_VARIANTS] = {}, vgprs[KERNEL_VARIANTS] = {}, sgprs = 0;
     uint32_t variant = KERNEL_LOCKSTEP;  // chosen per scene in set_scene
     uint32_t guided_mult = 16;           // run length = (left in shard) / (guided_mult * waves per shard); 16 measured best at 1/8-image launches
     uint32_t inline_steps = 0;           // 1 when several meshes share the list (many rays miss a mesh's root box: teapot +5..12 %), 0 for a single mesh (semesterbild -10 % otherwise)
@@ -249,10 +249,17 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     const bool has_mesh = n_mesh_prims != 0;
     ctx->inline_steps = n_mesh_prims >= 2 ? 1u : 0u;
     if (const char* e = std::getenv("MI355RT_INLINE_STEPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->inline_steps = (uint32_t)v; }
-    ctx->variant = has_mesh ? KERNEL_STATE_MACHINE : KERNEL_LOCKSTEP;
-    if (const char* e = std::getenv("MI355RT_KERNEL")) {            // A/B override (tools/): 0 lockstep, 1 lockstep+mesh, 2 state machine
+    bool simple_mats = true;                                         // only Lambertian (solid) / Emissive / Null?
+    for (uint32_t i = 0; i < sc->n_materials; ++i) {
+        const uint32_t k = sc->materials[i].kind;
+        simple_mats = simple_mats && (k == MI355RT_MAT_LAMBERT_SOLID || k == MI355RT_MAT_EMISSIVE || k == MI355RT_MAT_NULL);
+    }
+    ctx->variant = has_mesh ? KERNEL_STATE_MACHINE : (simple_mats ? KERNEL_LOCKSTEP_SIMPLE : KERNEL_LOCKSTEP);
+    if (const char* e = std::getenv("MI355RT_KERNEL")) {            // A/B override (tools/): 0 lockstep, 1 lockstep+mesh, 2 state machine, 3 lockstep simple
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 2 && (v != KERNEL_LOCKSTEP || !has_mesh)) ctx->variant = (uint32_t)v;
+        const bool ok = (v == KERNEL_LOCKSTEP && !has_mesh) || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE ||
+                        (v == KERNEL_LOCKSTEP_SIMPLE && !has_mesh && simple_mats);
+        if (ok) ctx->variant = (uint32_t)v;
     }
     ctx->trav_min = 24;
     if (const char* e = std::getenv("MI355RT_GUIDED_MULT")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->guided_mult = (uint32_t)v; }
@@ -287,7 +294,7 @@ int mi355rt_context_create(int hip_device, mi355rt_context** out_ctx) {
     if (!ctx) return fail(MI355RT_ERR_OOM, "host allocation failed");
     ctx->device = hip_device;
     ctx->cu_count = prop.multiProcessorCount;
-    for (uint32_t v = 0; v < 3; ++v) {
+    for (uint32_t v = 0; v < KERNEL_VARIANTS; ++v) {
         if (query_render_ctr_occupancy(v, &ctx->blocks_per_cu[v], &ctx->vgprs[v], &ctx->sgprs) != 0 || ctx->blocks_per_cu[v] <= 0) {
             delete ctx;
             return fail(MI355RT_ERR_HIP, std::string("kernel image not usable on this device (") + prop.gcnArchName + "); built for gfx950");

@@ -85,7 +85,9 @@ struct RenderParams {
 enum : uint32_t {
     KERNEL_LOCKSTEP = 0,         // no mesh at the top level: every lane traces a whole ray per iteration
     KERNEL_LOCKSTEP_MESH = 1,    // same loop with the per-lane BVH walk inlined (A/B reference for the state machine)
-    KERNEL_STATE_MACHINE = 2     // wave-voted TRAV / TOP / SHADE blocks (scenes with meshes)
+    KERNEL_STATE_MACHINE = 2,    // wave-voted TRAV / TOP / SHADE blocks (scenes with meshes)
+    KERNEL_LOCKSTEP_SIMPLE = 3,  // KERNEL_LOCKSTEP for scenes whose materials are only Lambertian (solid) / Emissive / Null
+    KERNEL_VARIANTS = 4
 };
 
 struct ResolveParams {

@@ -468,7 +468,9 @@ DI float beckmann_lambda(float a, float x) {                                    
 // Split in two so that the counter-mode kernels can run the unit-ball rejection of the Lambert-style bounce
 // wave-cooperatively between the halves: scatter_pre() decides everything except that direction (it sets
 // `diffuse`), diffuse_finish() turns the accepted unit-ball point into the scattered ray (material.rs:54-62).
-template <class Rng>
+// SIMPLE: the scene's materials are only Lambertian (solid) / Emissive / Null (checked on the host), so every
+// scattering material is the Lambert bounce and the other BSDFs -- which set the register peak -- are compiled out.
+template <bool SIMPLE, class Rng>
 DI bool scatter_pre(const DevMat* __restrict__ mats, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted, bool& diffuse_out) {
     const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
     const uint32_t kind = __float_as_uint(q0.x);
@@ -481,7 +483,7 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const float4 q0, const Hit&
     rng.begin_scatter();
     bool diffuse = false;                                                          // Lambert-style bounce shared by 3 materials
     atten = albedo;
-    if (kind == MI355RT_MAT_LAMBERT_SOLID) {                                       // material.rs:47-71
+    if (SIMPLE || kind == MI355RT_MAT_LAMBERT_SOLID) {                             // material.rs:47-71
         diffuse = true;
     } else if (kind == MI355RT_MAT_LAMBERT_CHECKER) {                              // tungsten/materials.rs:89-99
         const float4 q1 = m4[1];
@@ -589,7 +591,7 @@ DI void diffuse_finish(const Hit& h, f3 p, f3& new_o, f3& new_d) {              
 template <class Rng>
 DI bool surface_scatter(const DevMat* __restrict__ mats, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted) {
     bool diffuse = false;
-    if (!scatter_pre(mats, q0, h, rd_in, rng, new_o, new_d, atten, emitted, diffuse)) return false;
+    if (!scatter_pre<false>(mats, q0, h, rd_in, rng, new_o, new_d, atten, emitted, diffuse)) return false;
     if (diffuse) {
         f3 p; uint32_t j = 0;
         do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));
@@ -751,6 +753,7 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 // Must be called by the whole wave in uniform control flow (it ballots): lanes that are busy elsewhere
 // pass live = false and can_take = false and are left untouched.
 // Returns false when no lane is live afterwards and no work is left to deal.
+template <bool SIMPLE>
 DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     float4* __restrict__ radiance = reinterpret_cast<float4*>(P.radiance);
@@ -782,7 +785,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
             ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
             if (P.max_depth == 0u) { radiance[ps.sidx] = make_float4(0.f, 0.f, 0.f, 0.f); live = false; }   // depth == 0 -> BLACK
         } else {
-            scattered = scatter_pre(P.mats, q0, h, ps.rd, ps.rng, no, nd, atten, emitted, diffuse);
+            scattered = scatter_pre<SIMPLE>(P.mats, q0, h, ps.rd, ps.rng, no, nd, atten, emitted, diffuse);
         }
     }
     prof.mark(5);
@@ -819,6 +822,10 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
 #else
 #define MI355RT_OCC_LS
 #endif
+#ifndef MI355RT_OCC_LOCKSTEP_SIMPLE
+#define MI355RT_OCC_LOCKSTEP_SIMPLE 7
+#endif
+#define MI355RT_OCC_SIMPLE __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_LOCKSTEP_SIMPLE, MI355RT_OCC_LOCKSTEP_SIMPLE)))
 #ifndef MI355RT_OCC_SM
 #define MI355RT_OCC_SM 4
 #endif
@@ -833,8 +840,8 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
 // traces one full ray per loop iteration.  Used for scenes whose top level has no mesh (cornell, veach-mis):
 // all lanes walk the same primitive list, so the iteration is divergence-free up to the hit tests.
 // ===================================================================================================
-template <bool HAS_MESH>
-__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr(const RenderParams P) {
+template <bool HAS_MESH, bool SIMPLE>
+DI void render_ctr_lockstep(const RenderParams& P) {
     cprim_t prims = (cprim_t)(P.prims);
     const uint32_t lane = threadIdx.x & 63u;
     WorkCursor wc; wc.init();
@@ -851,7 +858,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr(con
         h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
         if (live) hit = hit_scene<HAS_MESH>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<SIMPLE>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
     }
 #ifdef MI355RT_STAMPS
@@ -866,6 +873,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr(con
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
     if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }
 }
+
+// Entry points: one body, instantiated per scene class so that each gets its own register budget.
+//   k_render_ctr_nomesh  any materials, no mesh in the list            (veach-mis)                6 waves/SIMD
+//   k_render_ctr_simple  Lambertian/Emissive/Null only, no mesh        (cornell: -3 % vs nomesh)   7 waves/SIMD
+//   k_render_ctr_mesh    lockstep with the per-lane BVH walk inlined   (A/B reference for the state machine)
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_nomesh(const RenderParams P) { render_ctr_lockstep<false, false>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_simple(const RenderParams P) { render_ctr_lockstep<false, true>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_mesh(const RenderParams P) { render_ctr_lockstep<true, false>(P); }
 
 // ===================================================================================================
 // k_render_ctr_sm -- the same path tracer as a wave-scheduled state machine, for scenes with meshes.
@@ -977,7 +992,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
         bool live = (state == ST_SHADE);
         const bool part = live || state == ST_IDLE;
         MI355RT_COUNT(3, __ballot(part));
-        shade_and_regenerate(P, wc, lane, live, part, any_hit, best, ps, n_paths, n_rays, prof);
+        shade_and_regenerate<false>(P, wc, lane, live, part, any_hit, best, ps, n_paths, n_rays, prof);
         if (part) {
             if (live) { state = ST_TOP; cursor = 0; closest = __builtin_inff(); any_hit = false; walk_done = false; }
             else state = ST_IDLE;
@@ -1091,9 +1106,10 @@ __global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
 // ---------------------------------------------------------------------------------------------------
 int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blocks, void* stream) {
     switch (variant) {
-        case KERNEL_LOCKSTEP:      hipLaunchKernelGGL(k_render_ctr<false>, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
-        case KERNEL_LOCKSTEP_MESH: hipLaunchKernelGGL(k_render_ctr<true>, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
-        default:                   hipLaunchKernelGGL(k_render_ctr_sm, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_LOCKSTEP:        hipLaunchKernelGGL(k_render_ctr_nomesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_LOCKSTEP_MESH:   hipLaunchKernelGGL(k_render_ctr_mesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_LOCKSTEP_SIMPLE: hipLaunchKernelGGL(k_render_ctr_simple, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        default:                     hipLaunchKernelGGL(k_render_ctr_sm, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
     }
     return (int)hipGetLastError();
 }
@@ -1107,9 +1123,10 @@ int launch_render_ref(const RefParams& p, void* stream) {
     return (int)hipGetLastError();
 }
 int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs) {
-    const void* fn = variant == KERNEL_LOCKSTEP ? reinterpret_cast<const void*>(k_render_ctr<false>)
-                   : variant == KERNEL_LOCKSTEP_MESH ? reinterpret_cast<const void*>(k_render_ctr<true>)
-                                                     : reinterpret_cast<const void*>(k_render_ctr_sm);
+    const void* fn = variant == KERNEL_LOCKSTEP ? reinterpret_cast<const void*>(k_render_ctr_nomesh)
+                   : variant == KERNEL_LOCKSTEP_MESH ? reinterpret_cast<const void*>(k_render_ctr_mesh)
+                   : variant == KERNEL_LOCKSTEP_SIMPLE ? reinterpret_cast<const void*>(k_render_ctr_simple)
+                                                       : reinterpret_cast<const void*>(k_render_ctr_sm);
     int nb = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK_THREADS, 0);
     if (e != hipSuccess) return (int)e;
