@@ -423,8 +423,8 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
             p.wave_times = nullptr;
             if (std::getenv("MI355RT_WAVE_TIMES")) {
                 ctx->wave_times_n = grid * waves_per_block;
-                if ((rc = ctx->wave_times.ensure((size_t)ctx->wave_times_n * 3))) return rc;
-                HIP_TRY(hipMemsetAsync(ctx->wave_times.p, 0, (size_t)ctx->wave_times_n * 24, stream));
+                if ((rc = ctx->wave_times.ensure((size_t)ctx->wave_times_n * WAVE_TIME_WORDS))) return rc;
+                HIP_TRY(hipMemsetAsync(ctx->wave_times.p, 0, (size_t)ctx->wave_times_n * WAVE_TIME_WORDS * 8, stream));
                 p.wave_times = ctx->wave_times.p;
             }
             grid_blocks = std::max(grid_blocks, grid);
@@ -471,7 +471,7 @@ int mi355rt_debug_read_wave_times(mi355rt_context* ctx, unsigned long long* out,
     if (!ctx || !out || !n_waves) return fail(MI355RT_ERR_INVALID, "null");
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n = std::min(capacity_waves, ctx->wave_times_n);
-    if (n) HIP_TRY(hipMemcpy(out, ctx->wave_times.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(hipMemcpy(out, ctx->wave_times.p, (size_t)n * WAVE_TIME_WORDS * 8, hipMemcpyDeviceToHost));
     *n_waves = n;
     return MI355RT_OK;
 }

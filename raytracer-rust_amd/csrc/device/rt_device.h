@@ -58,6 +58,7 @@ constexpr uint32_t BATCH_MIN = MI355RT_BATCH_MIN, BATCH_MAX = MI355RT_BATCH_MAX;
 constexpr uint32_t BLOCK_THREADS = 256;
 constexpr uint32_t WORK_SHARDS = 8;            // one work counter per XCD (power of two)
 constexpr uint32_t WORK_SHARD_STRIDE = 32;     // u32 words between counters: one 128-B line each
+constexpr uint32_t WAVE_TIME_WORDS = 6;        // diagnostic builds: per wave {start, end, paths, time work ran dry, iterations after, live lanes then}
 
 struct RenderParams {
     const DevPrim* prims; const DevMat* mats; const DevNode* nodes; const DevTri* tris;
@@ -66,7 +67,7 @@ struct RenderParams {
     float* radiance;             // float4 per band sample
     uint32_t* batch_counter;     // WORK_SHARDS counters (WORK_SHARD_STRIDE words apart): next unclaimed sample of each shard; zeroed per band
     unsigned long long* stats;   // [0] = paths started, [1] = rays traced
-    unsigned long long* wave_times;  // diagnostic builds only: per wave {start, end (100 MHz ticks), paths}; null otherwise
+    unsigned long long* wave_times;  // diagnostic builds only: WAVE_TIME_WORDS u64 per wave; null otherwise
     uint32_t n_prims, n_mats;
     float miss[3];
     DevCamera cam;

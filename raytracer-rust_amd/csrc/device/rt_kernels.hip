@@ -852,6 +852,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
     Prof prof; prof.begin();
 #ifdef MI355RT_STAMPS
     const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_dry = 0ull; uint32_t drain_iters = 0, live_at_dry = 0;
 #endif
     for (;;) {
         Hit h; bool hit = false;
@@ -860,6 +861,12 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         prof.mark(1);
         if (!shade_and_regenerate<SIMPLE>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
+#ifdef MI355RT_STAMPS
+        if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths
+            if (t_dry == 0ull) { t_dry = __builtin_amdgcn_s_memrealtime(); live_at_dry = (uint32_t)__popcll(__ballot(live)); }
+            ++drain_iters;
+        }
+#endif
     }
 #ifdef MI355RT_STAMPS
     if (lane == 0 && P.stats) for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
@@ -867,7 +874,10 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         const unsigned long long t_wave1 = __builtin_amdgcn_s_memrealtime();
         const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         const uint32_t np = wave_sum(n_paths);
-        if (lane == 0) { P.wave_times[3 * (size_t)wid] = t_wave0; P.wave_times[3 * (size_t)wid + 1] = t_wave1; P.wave_times[3 * (size_t)wid + 2] = np; }
+        if (lane == 0) {
+            unsigned long long* w = P.wave_times + WAVE_TIME_WORDS * (size_t)wid;
+            w[0] = t_wave0; w[1] = t_wave1; w[2] = np; w[3] = t_dry ? t_dry : t_wave1; w[4] = drain_iters; w[5] = live_at_dry;
+        }
     }
 #endif
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);

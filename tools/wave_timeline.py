@@ -14,12 +14,18 @@ out = torch.zeros(800 * 600, dtype=torch.int32, device="cuda")
 for parts in (1, 8):
     opt = abi.Options.make(strip_rows=5, n_parts=parts, part=0)
     for _ in range(3): st = ctx.render(out.data_ptr(), None, opt, None, want_stats=True)
-    buf = np.zeros(3 * 8192, np.uint64); n = C.c_uint32()
+    buf = np.zeros(6 * 8192, np.uint64); n = C.c_uint32()
     assert device.lib().mi355rt_debug_read_wave_times(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 8192, C.byref(n)) == 0
-    w = buf[:3 * n.value].reshape(-1, 3).astype(np.float64)
+    w = buf[:6 * n.value].reshape(-1, 6).astype(np.float64)
     t0 = w[:, 0].min(); start = (w[:, 0] - t0) / 100.0; end = (w[:, 1] - t0) / 100.0     # microseconds (100 MHz)
     print(f"parts={parts}: kernel {st.render_kernel_ms:.3f} ms, waves {n.value}, paths/wave mean {w[:,2].mean():.0f} min {w[:,2].min():.0f} max {w[:,2].max():.0f}")
     print("   wave start  us: p50 %.0f p99 %.0f max %.0f" % tuple(np.percentile(start, [50, 99, 100])))
     print("   wave end    us: p1 %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(end, [1, 10, 50, 90, 99, 100])))
     busy = (w[:, 1] - w[:, 0]).sum() / 100.0
     print("   sum(wave lifetimes) / (waves * makespan) = %.3f" % (busy / (n.value * end.max())))
+    dry = (w[:, 3] - t0) / 100.0
+    print("   work ran dry us: p1 %.0f p50 %.0f p99 %.0f max %.0f" % tuple(np.percentile(dry, [1, 50, 99, 100])))
+    print("   drain (end - dry) us: p10 %.0f p50 %.0f p90 %.0f max %.0f | iterations p50 %.0f p90 %.0f max %.0f | live lanes at dry p50 %.0f" % (
+        *np.percentile(end - dry, [10, 50, 90, 100]), *np.percentile(w[:, 4], [50, 90, 100]), np.percentile(w[:, 5], 50)))
+    d = end - dry; it = np.maximum(w[:, 4], 1)
+    print("   us per drain iteration: p10 %.1f p50 %.1f p90 %.1f" % tuple(np.percentile(d / it, [10, 50, 90])))
