@@ -206,6 +206,29 @@ int  mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* options
                             void* d_out_packed_rgb, void* d_out_linear_rgb_or_null,
                             void* hip_stream, mi355rt_stats* stats_or_null);
 
+/* Progressive rendering (the sample loop of src/renderer.rs:93-101 cut into chunks): trace samples
+ * [sample_begin, sample_end) of every selected pixel and add them, in sample order, to the running
+ * sums in `d_accum` (DEVICE, 4 floats per selected pixel, row-major over the selected rows; read only
+ * when sample_begin > 0, always written).  The outputs hold the image of the first `sample_end`
+ * samples (sum * 1/sample_end, renderer.rs:103).  Because every draw is addressed by (row, x, sample,
+ * ray) and the f32 additions happen in the same order, a sequence of calls covering 0..N is
+ * bit-identical to one mi355rt_context_render with samples_per_pixel == N -- for any chunking.
+ * settings.samples_per_pixel is not consulted.  MI355RT_RNG_CTR only.                              */
+int  mi355rt_context_render_progressive(mi355rt_context* ctx, const mi355rt_options* options_or_null,
+                                        uint32_t sample_begin, uint32_t sample_end, void* d_accum,
+                                        void* d_out_packed_rgb, void* d_out_linear_rgb_or_null,
+                                        void* hip_stream, mi355rt_stats* stats_or_null);
+
+/* One-shot progressive render with HOST buffers: mi355rt_render in chunks of `chunk_spp` samples.  After
+ * every chunk `on_chunk_or_null(user, samples_done, samples_total, out_packed_rgb)` sees the image so far
+ * (what the reference's preview window, src/main.rs:60-75, would show); a non-zero return stops early and
+ * leaves the image of `samples_done` samples in the outputs.  The final image equals mi355rt_render's.   */
+typedef int (*mi355rt_progress_fn)(void* user, uint32_t samples_done, uint32_t samples_total, const uint32_t* packed_rgb);
+int  mi355rt_render_progressive(const mi355rt_scene* scene, const mi355rt_camera* camera,
+                                const mi355rt_settings* settings, const mi355rt_options* options_or_null,
+                                uint32_t chunk_spp, mi355rt_progress_fn on_chunk_or_null, void* user,
+                                uint32_t* out_packed_rgb, float* out_linear_rgb_or_null, mi355rt_stats* stats_or_null);
+
 /* Kernel timing without extra synchronisation: while enabled, every mi355rt_context_render call that
  * passes stats == NULL records HIP events around its kernels on the caller's stream.  After the
  * caller has synchronised that stream, read_timing returns the summed kernel durations and the
@@ -251,6 +274,9 @@ const mi355rt_settings* mi355rt_loaded_scene_settings(const mi355rt_loaded_scene
 
 /* save_image's pixel conversion (src/renderer.rs:125-143) into an 8-bit RGB PNG.                  */
 int mi355rt_write_png(const char* path, const uint32_t* packed_rgb, uint32_t width, uint32_t height);
+
+/* The pre-gamma f32 image (out_linear_rgb) as a little-endian Portable FloatMap, for parity tooling.  */
+int mi355rt_write_pfm(const char* path, const float* linear_rgb, uint32_t width, uint32_t height);
 
 const char* mi355rt_host_last_error(void);
 

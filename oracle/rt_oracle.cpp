@@ -536,6 +536,9 @@ bool cube_hit(const mi355rt_primitive& p, const Ray& ray, float t_min, float t_m
 }
 
 // mesh/mesh_object.rs:263-329
+// Diagnostic (tools/): histogram of BVH nodes visited per mesh walk, filled when oracle_walk_histogram() armed it.
+constexpr uint64_t WALK_HIST_BINS = 512;
+static unsigned long long* g_walk_hist = nullptr;
 bool mesh_hit(const mi355rt_primitive& p, const MeshData& mesh, const Ray& ray_world, float t_min_world,
               float t_max_world, HitRecord& h, Counters& c) {
     M4 o2w, w2o; std::memcpy(o2w.m, p.data, 64); std::memcpy(w2o.m, p.data + 16, 64);
@@ -545,7 +548,10 @@ bool mesh_hit(const mi355rt_primitive& p, const MeshData& mesh, const Ray& ray_w
     V3 ray_origin_obj = {oh[0], oh[1], oh[2]}, ray_direction_obj = {dh[0], dh[1], dh[2]};
     Ray ray_obj = ray_new(ray_origin_obj, normalized(ray_direction_obj));
     HitRecord rec;
-    if (!bvh_intersect_recursive(mesh.bvh.get(), ray_obj, mesh.tris, t_min_world, t_max_world, rec, c)) return false;
+    const uint64_t nodes_before = c.bvh_nodes;
+    const bool walk_hit = bvh_intersect_recursive(mesh.bvh.get(), ray_obj, mesh.tris, t_min_world, t_max_world, rec, c);
+    if (g_walk_hist) __atomic_fetch_add(&g_walk_hist[std::min<uint64_t>(c.bvh_nodes - nodes_before, WALK_HIST_BINS - 1)], 1ull, __ATOMIC_RELAXED);
+    if (!walk_hit) return false;
     float pw[4], nw[4];
     mat_mul_vec4(o2w, rec.position.x, rec.position.y, rec.position.z, 1.0f, pw);
     mat_transpose_mul_vec4(w2o, rec.normal.x, rec.normal.y, rec.normal.z, 0.0f, nw);
@@ -862,6 +868,8 @@ struct oracle_counters {
 
 // renderer.rs:67-123 -- render_scene.  fold: -1 = mode default (REF -> tail-first recursion,
 // CTR -> forward throughput), 0 = tail, 1 = forward.
+// Arm (hist != NULL, WALK_HIST_BINS entries, caller-owned) or disarm (NULL) the walk-length histogram.
+void oracle_walk_histogram(unsigned long long* hist) { g_walk_hist = hist; }
 int oracle_render(const mi355rt_scene* scene_in, const mi355rt_camera* cam, const mi355rt_settings* st,
                   const mi355rt_options* opt, int n_threads, int fold, uint32_t* out_packed, float* out_linear,
                   oracle_counters* counters_out) {

@@ -330,8 +330,9 @@ int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, 
     return MI355RT_OK;
 }
 
-int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, void* d_out_packed, void* d_out_linear,
-                           void* hip_stream, mi355rt_stats* stats) {
+// Samples [s0, s1) of every selected pixel.  The classic call is (0, settings.spp, no accumulator).
+static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint32_t s0, uint32_t s1, void* d_accum,
+                          void* d_out_packed, void* d_out_linear, void* hip_stream, mi355rt_stats* stats) {
     if (!ctx || !ctx->have_scene) return fail(MI355RT_ERR_INVALID, "context has no scene");
     if (!d_out_packed) return fail(MI355RT_ERR_INVALID, "d_out_packed is null");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -362,6 +363,8 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
     uint32_t n_bands = 0, grid_blocks = 0, block_threads = 0;
 
     if (rng_mode == MI355RT_RNG_REF) {
+        if (d_accum || s0 != 0 || s1 != st.samples_per_pixel)
+            return fail(MI355RT_ERR_INVALID, "progressive rendering needs MI355RT_RNG_CTR (the reference stream of a row is sequential over its pixels)");
         if ((rc = ctx->fold_stack.ensure((size_t)n_rows * std::max(st.max_depth, 1u) * 3))) return rc;
         RefParams rp{};
         rp.prims = ctx->prims.p; rp.mats = ctx->mats.p; rp.nodes = ctx->nodes.p; rp.tris = ctx->tris.p; rp.rows = ctx->rows.p;
@@ -382,7 +385,7 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         n_bands = 1; grid_blocks = n_rows; block_threads = 64;
     } else {
         // ---- band plan: the radiance workspace holds band_pixels * spp float4 ----
-        const uint64_t spp = st.samples_per_pixel;
+        const uint64_t spp = s1 - s0;                                 // samples per pixel in THIS launch
         const uint64_t total_pixels = (uint64_t)n_rows * st.width;
         uint64_t ws_cap = (opt && opt->workspace_bytes) ? opt->workspace_bytes : (32ull << 30);   // 288 GB of HBM: default = the 2^31-sample band limit; only what a band needs is allocated
         uint64_t max_samples = std::min<uint64_t>(ws_cap / 16, (1ull << 31) - 2 * BATCH_MAX);
@@ -400,13 +403,14 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         p.radiance = ctx->radiance.p; p.stats = ctx->stats.p;
         p.n_prims = ctx->n_prims; p.n_mats = ctx->n_mats;
         std::memcpy(p.miss, ctx->miss, 12); p.cam = ctx->cam;
-        p.width = st.width; p.height = st.height; p.spp = st.samples_per_pixel; p.max_depth = st.max_depth;
-        p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
-        magic_div(st.samples_per_pixel, p.spp_mul, p.spp_shift); magic_div(st.width, p.width_mul, p.width_shift);
+        p.width = st.width; p.height = st.height; p.spp = (uint32_t)spp; p.max_depth = st.max_depth;
+        p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.sample0 = s0;
+        magic_div((uint32_t)spp, p.spp_mul, p.spp_shift); magic_div(st.width, p.width_mul, p.width_shift);
         p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;
         ResolveParams r{};
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
-        r.spp = st.samples_per_pixel; r.inv_spp = 1.0f / (float)st.samples_per_pixel;     // renderer.rs:85
+        r.spp = (uint32_t)spp; r.inv_spp = 1.0f / (float)s1;                             // renderer.rs:85
+        r.accum = (float*)d_accum; r.accum_load = s0 != 0 ? 1u : 0u;
         const uint32_t resident = (uint32_t)(ctx->cu_count * ctx->blocks_per_cu[ctx->variant]);
         block_threads = BLOCK_THREADS;
         std::vector<float> band_ms;
@@ -457,6 +461,19 @@ int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, voi
         stats->bands = n_bands; stats->grid_blocks = grid_blocks; stats->block_threads = block_threads;
     }
     return MI355RT_OK;
+}
+
+int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, void* d_out_packed, void* d_out_linear,
+                           void* hip_stream, mi355rt_stats* stats) {
+    if (!ctx || !ctx->have_scene) return fail(MI355RT_ERR_INVALID, "context has no scene");
+    return render_samples(ctx, opt, 0, ctx->settings.samples_per_pixel, nullptr, d_out_packed, d_out_linear, hip_stream, stats);
+}
+
+int mi355rt_context_render_progressive(mi355rt_context* ctx, const mi355rt_options* opt, uint32_t sample_begin, uint32_t sample_end,
+                                       void* d_accum, void* d_out_packed, void* d_out_linear, void* hip_stream, mi355rt_stats* stats) {
+    if (!d_accum) return fail(MI355RT_ERR_INVALID, "d_accum is null");
+    if (sample_end <= sample_begin) return fail(MI355RT_ERR_INVALID, "sample_end must be greater than sample_begin");
+    return render_samples(ctx, opt, sample_begin, sample_end, d_accum, d_out_packed, d_out_linear, hip_stream, stats);
 }
 
 // Diagnostic hook (not part of the public header): the 16 raw device counters of the last render.
@@ -523,6 +540,56 @@ int mi355rt_render(const mi355rt_scene* scene, const mi355rt_camera* camera, con
     }
     if (d_packed) (void)hipFree(d_packed);
     if (d_linear) (void)hipFree(d_linear);
+    std::string keep = g_err;
+    mi355rt_context_destroy(ctx);
+    g_err = keep;
+    return rc;
+}
+
+// Host-buffer progressive render: what a preview window (src/main.rs:60-75) would be fed from.
+int mi355rt_render_progressive(const mi355rt_scene* scene, const mi355rt_camera* camera, const mi355rt_settings* settings,
+                               const mi355rt_options* opt, uint32_t chunk_spp, mi355rt_progress_fn on_chunk, void* user,
+                               uint32_t* out_packed, float* out_linear, mi355rt_stats* stats) {
+    if (!out_packed) return fail(MI355RT_ERR_INVALID, "out_packed_rgb is null");
+    if (chunk_spp == 0) return fail(MI355RT_ERR_INVALID, "chunk_spp is 0");
+    int rc = check_settings(settings); if (rc) return rc;
+    uint32_t n_rows = 0;
+    rc = mi355rt_rows_selected(settings, opt, &n_rows); if (rc) return rc;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(MI355RT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    mi355rt_context* ctx = nullptr;
+    rc = mi355rt_context_create(dev, &ctx); if (rc) return rc;
+    rc = mi355rt_context_set_scene(ctx, scene, camera, settings);
+    uint32_t* d_packed = nullptr; float* d_linear = nullptr; float* d_accum = nullptr;
+    const size_t npix = (size_t)n_rows * settings->width;
+    mi355rt_stats total{};
+    if (!rc && npix) {
+        if (hipMalloc((void**)&d_packed, npix * 4) != hipSuccess) rc = fail(MI355RT_ERR_OOM, "hipMalloc(out_packed)");
+        if (!rc && hipMalloc((void**)&d_accum, npix * 16) != hipSuccess) rc = fail(MI355RT_ERR_OOM, "hipMalloc(accum)");
+        if (!rc && out_linear && hipMalloc((void**)&d_linear, npix * 12) != hipSuccess) rc = fail(MI355RT_ERR_OOM, "hipMalloc(out_linear)");
+        const uint32_t spp = settings->samples_per_pixel;
+        for (uint32_t s0 = 0; !rc && s0 < spp; ) {
+            const uint32_t s1 = s0 + std::min(chunk_spp, spp - s0);
+            mi355rt_stats st{};
+            rc = mi355rt_context_render_progressive(ctx, opt, s0, s1, d_accum, d_packed, d_linear, nullptr, &st);
+            if (rc) break;
+            total.render_kernel_ms += st.render_kernel_ms; total.resolve_kernel_ms += st.resolve_kernel_ms; total.total_ms += st.total_ms;
+            total.samples += st.samples; total.rays += st.rays; total.bands += st.bands;
+            total.rows_rendered = st.rows_rendered; total.grid_blocks = st.grid_blocks; total.block_threads = st.block_threads;
+            total.kernel_vgprs = st.kernel_vgprs; total.kernel_sgprs = st.kernel_sgprs;
+            const bool last = s1 == spp;
+            if (on_chunk || last) {
+                if (hipMemcpy(out_packed, d_packed, npix * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MI355RT_ERR_HIP, "copy back packed"); break; }
+                if (out_linear && hipMemcpy(out_linear, d_linear, npix * 12, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MI355RT_ERR_HIP, "copy back linear"); break; }
+            }
+            s0 = s1;
+            if (on_chunk && on_chunk(user, s1, spp, out_packed) != 0) break;            // the caller stops early: outputs hold s1 samples
+        }
+    }
+    if (stats) *stats = total;
+    if (d_packed) (void)hipFree(d_packed);
+    if (d_linear) (void)hipFree(d_linear);
+    if (d_accum) (void)hipFree(d_accum);
     std::string keep = g_err;
     mi355rt_context_destroy(ctx);
     g_err = keep;

@@ -77,6 +77,7 @@ struct RenderParams {
     uint32_t guided_div;         // run length = (left in the shard) / guided_div
     uint32_t shard_samples;      // samples per shard: ceil(band_samples / WORK_SHARDS)
     uint32_t seed_lo, seed_hi;
+    uint32_t sample0;            // index of the first sample of this launch within its pixel (progressive rendering; 0 otherwise)
     uint32_t spp_mul, spp_shift, width_mul, width_shift;   // magic pairs for n / spp and n / width (n < 2^31)
     uint32_t trav_min;           // state-machine kernel: run BVH rounds while at least this many lanes are walking
     uint32_t inline_steps;       // state-machine kernel: box tests taken right at mesh setup (short walks skip the TRAV round trip)
@@ -95,8 +96,10 @@ struct ResolveParams {
     const float* radiance;       // float4 per band sample
     uint32_t* out_packed;        // local pixels, 0x00RRGGBB
     float* out_linear;           // local pixels * 3, may be null
+    float* accum;                // optional running per-pixel sums (float4 per local pixel): progressive rendering
+    uint32_t accum_load;         // 1: start from accum[] (samples before this launch), 0: start from zero
     uint32_t band_pixel0, band_pixels, spp;
-    float inv_spp;
+    float inv_spp;               // 1 / (samples accumulated so far including this launch)
 };
 
 struct RefParams {               // MI355RT_RNG_REF: one lane per selected row

@@ -692,7 +692,7 @@ DI void start_path(const RenderParams& P, uint32_t sidx, RngCtr& rng, uint32_t& 
     px = pix - jrow * P.width;
     py = P.rows[jrow];
     const uint64_t ykey = (uint64_t)py + (((uint64_t)P.seed_hi << 32) | (uint64_t)P.seed_lo);
-    rng.start((uint32_t)ykey, (uint32_t)(ykey >> 32), px, s);
+    rng.start((uint32_t)ykey, (uint32_t)(ykey >> 32), px, s + P.sample0);
 }
 
 // Per-lane path state shared by both kernels.
@@ -1039,6 +1039,8 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveParams P) {
     float4* __restrict__ mine = stage[wave];
     typedef float v4f __attribute__((ext_vector_type(4)));
     f3 acc = mk(0.f, 0.f, 0.f);
+    float4* __restrict__ accum = reinterpret_cast<float4*>(P.accum);
+    if (accum && P.accum_load && p < P.band_pixels) { const float4 a = accum[(size_t)P.band_pixel0 + p]; acc = mk(a.x, a.y, a.z); }   // the sum goes on where it stopped
     const uint32_t sub_pix = lane >> 4, sub_s = lane & 15u;
     for (uint32_t c = 0; c < P.spp; c += RES_CHUNK) {
         const uint32_t s = c + sub_s;
@@ -1059,6 +1061,7 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveParams P) {
     if (p >= P.band_pixels) return;
     const f3 pixel = acc * P.inv_spp;                            // renderer.rs:103
     const size_t o = (size_t)P.band_pixel0 + p;
+    if (accum) accum[o] = make_float4(acc.x, acc.y, acc.z, 0.0f);
     if (P.out_linear) { P.out_linear[3 * o] = pixel.x; P.out_linear[3 * o + 1] = pixel.y; P.out_linear[3 * o + 2] = pixel.z; }
     P.out_packed[o] = color_to_u32(sqrt3(pixel));                // renderer.rs:112-120
 }

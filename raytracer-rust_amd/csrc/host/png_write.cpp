@@ -48,3 +48,17 @@ extern "C" int mi355rt_write_png(const char* path, const uint32_t* packed, uint3
     std::fclose(f);
     return ok ? MI355RT_OK : set_error(MI355RT_ERR_IO, "write_png: short write");
 }
+
+// Linear f32 dump for parity tooling: Portable FloatMap, "PF", little-endian, rows BOTTOM-UP as
+// the format prescribes; `linear_rgb` is the pre-gamma mean image (row 0 = top) that mi355rt_render returns.
+extern "C" int mi355rt_write_pfm(const char* path, const float* linear_rgb, uint32_t width, uint32_t height) {
+    using mi355rt_host::set_error;
+    if (!path || !linear_rgb || width == 0 || height == 0) return set_error(MI355RT_ERR_INVALID, "write_pfm: bad argument");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return set_error(MI355RT_ERR_IO, std::string("write_pfm: cannot open ") + path);
+    bool ok = std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height) > 0;
+    for (uint32_t y = height; ok && y-- > 0; )
+        ok = std::fwrite(linear_rgb + (size_t)y * width * 3, sizeof(float), (size_t)width * 3, f) == (size_t)width * 3;
+    std::fclose(f);
+    return ok ? MI355RT_OK : set_error(MI355RT_ERR_IO, "write_pfm: short write");
+}

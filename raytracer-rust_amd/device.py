@@ -11,8 +11,8 @@ import numpy as np
 
 from . import abi, build
 
-EXPORTS = ["mi355rt_render", "mi355rt_context_create", "mi355rt_context_destroy", "mi355rt_context_set_scene",
-           "mi355rt_rows_selected", "mi355rt_context_render", "mi355rt_context_set_timing", "mi355rt_context_read_timing",
+EXPORTS = ["mi355rt_render", "mi355rt_render_progressive", "mi355rt_context_create", "mi355rt_context_destroy", "mi355rt_context_set_scene",
+           "mi355rt_rows_selected", "mi355rt_context_render", "mi355rt_context_render_progressive", "mi355rt_context_set_timing", "mi355rt_context_read_timing",
            "mi355rt_last_error", "mi355rt_abi_version"]
 
 _lib = None
@@ -41,6 +41,9 @@ def lib():
         L.mi355rt_context_render.restype = C.c_int
         L.mi355rt_context_render.argtypes = [C.c_void_p, C.POINTER(abi.Options), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.POINTER(abi.Stats)]
+        L.mi355rt_context_render_progressive.restype = C.c_int
+        L.mi355rt_context_render_progressive.argtypes = [C.c_void_p, C.POINTER(abi.Options), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                         C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
         L.mi355rt_context_set_timing.restype = C.c_int
         L.mi355rt_context_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.mi355rt_context_read_timing.restype = C.c_int
@@ -105,6 +108,16 @@ class Context:
                                             C.c_void_p(d_out_packed), C.c_void_p(d_out_linear) if d_out_linear else None,
                                             C.c_void_p(stream) if stream else None,
                                             C.byref(stats) if want_stats else None), "mi355rt_context_render")
+        return stats
+
+    def render_progressive(self, sample_begin, sample_end, d_accum, d_out_packed, d_out_linear=None, options=None, stream=None, want_stats=False):
+        """Samples [sample_begin, sample_end) added to the running sums in d_accum (float4 per selected pixel, device address)."""
+        stats = abi.Stats() if want_stats else None
+        _check(lib().mi355rt_context_render_progressive(self._h, C.byref(options) if options is not None else None,
+                                                        int(sample_begin), int(sample_end), C.c_void_p(d_accum), C.c_void_p(d_out_packed),
+                                                        C.c_void_p(d_out_linear) if d_out_linear else None,
+                                                        C.c_void_p(stream) if stream else None,
+                                                        C.byref(stats) if stats is not None else None), "mi355rt_context_render_progressive")
         return stats
 
     def set_timing(self, enable=True):

@@ -91,3 +91,18 @@ def test_png_writer_roundtrip(native, tmp_path):
     host.write_png(path, img, 13, 7)
     got = np.array(Image.open(path).convert("RGB")).astype(np.uint32)
     assert np.array_equal((got[..., 0] << 16) | (got[..., 1] << 8) | got[..., 2], img)
+
+
+def test_pfm_writer_roundtrip(native, tmp_path):
+    """Portable FloatMap: 'PF', width height, negative scale = little-endian, rows bottom-up, raw f32 (bit-preserving)."""
+    host, _ = native
+    rng = np.random.default_rng(2)
+    img = rng.standard_normal((5, 9, 3)).astype(np.float32)
+    img[0, 0] = [np.inf, -0.0, np.float32(1e-42)]                  # special values and a denormal survive untouched
+    path = str(tmp_path / "x.pfm")
+    host.write_pfm(path, img, 9, 5)
+    raw = open(path, "rb").read()
+    header = b"PF\n9 5\n-1.0\n"
+    assert raw.startswith(header) and len(raw) == len(header) + 5 * 9 * 3 * 4
+    got = np.frombuffer(raw[len(header):], dtype="<f4").reshape(5, 9, 3)[::-1]
+    assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
