@@ -262,7 +262,9 @@ typedef struct mi355rt_loaded_scene mi355rt_loaded_scene;
 typedef struct mi355rt_load_overrides {
     uint32_t width, height, samples_per_pixel, max_depth;
     uint32_t skip_unknown_primitives;  /* 0 = hard error like serde (parser.rs:135-165), 1 = skip   */
-    uint32_t _pad;
+    uint32_t wo3_four_index_stride;    /* 0 = the reference's reader, which steps 3 u32 per triangle through a file that stores 4
+                                        *     (mesh_object.rs:190-192: ~1/4 of the triangles survive);
+                                        * 1 = opt-in fix: read (v0, v1, v2, material) per triangle.  Changes the image.               */
 } mi355rt_load_overrides;
 
 int  mi355rt_scene_load_json(const char* json_path, const mi355rt_load_overrides* overrides_or_null,

@@ -227,16 +227,20 @@ def load_obj(path):
     return _triangles_from_indexed(verts, idx3[ok])
 
 
-def load_wo3(path):
+def load_wo3(path, four_index_stride=False):
     """Mesh::from_wo3 (mesh_object.rs:141-259) INCLUDING its stride bug (SURVEY App. B-2): the file
-    stores 4 u32 per triangle, the reference reads 3 per iteration for num_tris iterations."""
+    stores 4 u32 per triangle, the reference reads 3 per iteration for num_tris iterations.
+    four_index_stride=True is the opt-in fix (v0, v1, v2, material per triangle)."""
     b = open(path, "rb").read()
     nv = struct.unpack_from("<Q", b, 0)[0]
     vraw = np.frombuffer(b, dtype="<f4", count=nv * 8, offset=8).reshape(nv, 8)
     verts = vraw[:, 0:3].astype(F)
     off = 8 + nv * 32
     nt = struct.unpack_from("<Q", b, off)[0]
-    words = np.frombuffer(b, dtype="<u4", count=nt * 3, offset=off + 8).reshape(nt, 3).astype(np.int64)
+    if four_index_stride:
+        words = np.frombuffer(b, dtype="<u4", count=nt * 4, offset=off + 8).reshape(nt, 4)[:, :3].astype(np.int64)
+    else:
+        words = np.frombuffer(b, dtype="<u4", count=nt * 3, offset=off + 8).reshape(nt, 3).astype(np.int64)
     ok = np.all(words < nv, axis=1)
     return _triangles_from_indexed(verts, words[ok])
 
@@ -478,7 +482,7 @@ class LoadedScene:
         return self
 
 
-def load_scene(json_path, width=0, height=0, spp=0, max_depth=0, skip_unknown_primitives=False):
+def load_scene(json_path, width=0, height=0, spp=0, max_depth=0, skip_unknown_primitives=False, wo3_four_index_stride=False):
     """load_scene_from_json (parser.rs:245-815).  Non-zero overrides replace the parsed settings
     (applied before the aspect ratio is derived, as if the JSON had carried them)."""
     with open(json_path, "r") as f:
@@ -599,7 +603,7 @@ def load_scene(json_path, width=0, height=0, spp=0, max_depth=0, skip_unknown_pr
             m = _object_matrix(p["transform"])
             path = os.path.join(scene_dir, p["file"])
             try:
-                tris = load_wo3(path) if p["file"].endswith(".wo3") else load_obj(path)
+                tris = load_wo3(path, wo3_four_index_stride) if p["file"].endswith(".wo3") else load_obj(path)
             except OSError:
                 tris = np.zeros((0, 12), F)
             if tris.shape[0] == 0:                          # load error -> object dropped (parser.rs:685-698)

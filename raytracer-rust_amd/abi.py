@@ -79,7 +79,7 @@ class Stats(C.Structure):
 
 class LoadOverrides(C.Structure):
     _fields_ = [("width", u32), ("height", u32), ("samples_per_pixel", u32), ("max_depth", u32),
-                ("skip_unknown_primitives", u32), ("_pad", u32)]
+                ("skip_unknown_primitives", u32), ("wo3_four_index_stride", u32)]
 
 
 STRUCT_SIZES = {  # what sizeof() must report in C

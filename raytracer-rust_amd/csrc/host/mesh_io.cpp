@@ -61,7 +61,8 @@ int load_obj(const std::string& path, std::vector<mi355rt_triangle>& tris) {
 // Mesh::from_wo3 INCLUDING its index-stride bug: the file stores 4 u32 per
 // triangle (v0, v1, v2, material); the reference reads 3 u32 per iteration for num_tris iterations
 // (mesh_object.rs:190-192), i.e. it consumes the first 3/4 of the index stream with a sliding phase.
-int load_wo3(const std::string& path, std::vector<mi355rt_triangle>& tris) {
+// `four_index_stride` (opt-in, never the default: it changes the image) reads the file as Tungsten wrote it.
+int load_wo3(const std::string& path, std::vector<mi355rt_triangle>& tris, bool four_index_stride) {
     std::ifstream f(path, std::ios::binary);
     if (!f) return set_error(MI355RT_ERR_IO, "cannot open WO3 " + path);
     std::vector<unsigned char> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -73,14 +74,15 @@ int load_wo3(const std::string& path, std::vector<mi355rt_triangle>& tris) {
     const size_t toff = voff + (size_t)nv * 32;
     if (!rd_u64(toff, nt)) return set_error(MI355RT_ERR_IO, "WO3 truncated triangle header");
     const size_t ioff = toff + 8;
-    if (nt > (b.size() - ioff) / 12) return set_error(MI355RT_ERR_IO, "WO3 truncated indices");   // read_u32 would hit EOF -> Err
+    const size_t stride = four_index_stride ? 16 : 12;
+    if (nt > (b.size() - ioff) / stride) return set_error(MI355RT_ERR_IO, "WO3 truncated indices");   // read_u32 would hit EOF -> Err
     std::vector<V3> verts((size_t)nv);
     for (size_t i = 0; i < (size_t)nv; ++i) {
         float p[3]; std::memcpy(p, b.data() + voff + i * 32, 12);      // position, then normal(3) + uv(2) skipped
         verts[i] = {p[0], p[1], p[2]};
     }
     for (size_t i = 0; i < (size_t)nt; ++i) {
-        uint32_t id[3]; std::memcpy(id, b.data() + ioff + i * 12, 12);
+        uint32_t id[3]; std::memcpy(id, b.data() + ioff + i * stride, 12);
         if (id[0] >= nv || id[1] >= nv || id[2] >= nv) continue;         // mesh_object.rs:202-214
         mi355rt_triangle t;
         if (make_triangle(verts[id[0]], verts[id[1]], verts[id[2]], t)) tris.push_back(t);

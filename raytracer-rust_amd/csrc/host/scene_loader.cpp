@@ -323,7 +323,7 @@ void load_impl(const std::string& json_path, const mi355rt_load_overrides* ov, m
             const std::string path = scene_dir + "/" + file->str;
             std::vector<mi355rt_triangle> tris;
             const bool wo3 = file->str.size() >= 4 && file->str.compare(file->str.size() - 4, 4, ".wo3") == 0;
-            const int rc = wo3 ? load_wo3(path, tris) : load_obj(path, tris);
+            const int rc = wo3 ? load_wo3(path, tris, ov && ov->wo3_four_index_stride) : load_obj(path, tris);
             if (rc != MI355RT_OK || tris.empty()) continue;                       // "Error loading ... mesh" -> object dropped (parser.rs:685-698)
             mi355rt_mesh mesh; std::memset(&mesh, 0, sizeof mesh);
             std::vector<mi355rt_bvh_node> nodes; std::vector<uint32_t> idx; uint32_t md = 0;

@@ -96,8 +96,8 @@ def attach_bvh(scene):
 class LoadedScene:
     """A scene loaded by the C++ host loader (mi355rt_scene_load_json)."""
 
-    def __init__(self, path, width=0, height=0, spp=0, max_depth=0, skip_unknown_primitives=False):
-        ov = abi.LoadOverrides(width, height, spp, max_depth, 1 if skip_unknown_primitives else 0, 0)
+    def __init__(self, path, width=0, height=0, spp=0, max_depth=0, skip_unknown_primitives=False, wo3_four_index_stride=False):
+        ov = abi.LoadOverrides(width, height, spp, max_depth, 1 if skip_unknown_primitives else 0, 1 if wo3_four_index_stride else 0)
         h = C.c_void_p()
         _check(lib().mi355rt_scene_load_json(os.fsencode(path), C.byref(ov), C.byref(h)), f"mi355rt_scene_load_json({path})")
         self._h = h

@@ -138,3 +138,15 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, monkeypa
     _, vl3, vst3 = device.render(sv, sv.camera, sv.settings, abi.Options.make())
     assert vst.kernel_vgprs == st0.kernel_vgprs == vst3.kernel_vgprs
     assert np.array_equal(vl.view(np.uint32), vl3.view(np.uint32))
+
+
+def test_fixed_wo3_reader_scene_is_bit_identical_to_the_oracle(native, oracle_mod, abi):
+    """Opt-in loader fix (4 u32 per WO3 triangle): a different triangle set through the same kernels -- the whole teapot."""
+    from oracle import scene_loader
+    from conftest import SCENES
+    host, device = native
+    sc = scene_loader.load_scene(SCENES["teapot"], skip_unknown_primitives=True, wo3_four_index_stride=True, width=80, height=60, spp=4, max_depth=12)
+    sc._keep = host.attach_bvh(sc)
+    gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make())
+    op, ol, cnt = oracle_mod.render(sc, sc.camera, sc.settings, abi.Options.make())
+    assert st.rays == cnt.rays and np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op)

@@ -34,6 +34,29 @@ def test_cpp_loader_equals_oracle_loader(name, native, abi):
     assert list(sa.miss_color) == [0.5, 0.5, 0.5]
 
 
+def test_wo3_four_index_reader_is_opt_in_and_agrees_between_loaders(native, abi):
+    """mesh_object.rs:190-192 steps 3 u32 per triangle through a file that stores 4.  The default
+    reproduces that; wo3_four_index_stride=1 reads every triangle.  Both loaders must agree bit-for-bit in both modes."""
+    host, _ = native
+    from oracle import scene_loader
+    kw = dict(skip_unknown_primitives=True)
+    bug = host.LoadedScene(SCENES["teapot"], **kw)
+    fix = host.LoadedScene(SCENES["teapot"], wo3_four_index_stride=True, **kw)
+    ofix = scene_loader.load_scene(SCENES["teapot"], wo3_four_index_stride=True, **kw)
+    assert bug.c.n_triangles == 19369 + 11968                           # SURVEY 8(d) cfg 3: what survives the 3-index stride
+    assert fix.c.n_triangles == ofix.c.n_triangles > 2 * bug.c.n_triangles
+    assert np.array_equal(_bytes(fix.c.triangles, fix.c.n_triangles, abi.Triangle), _bytes(ofix.c.triangles, ofix.c.n_triangles, abi.Triangle))
+    import struct
+    total = 0
+    for m in ("Mesh000.wo3", "Mesh001.wo3"):
+        b = open(os.path.join(os.path.dirname(SCENES["teapot"]), "models", m), "rb").read()
+        nv = struct.unpack_from("<Q", b, 0)[0]
+        nt = struct.unpack_from("<Q", b, 8 + nv * 32)[0]
+        assert len(b) == 8 + nv * 32 + 8 + nt * 16                       # the file really holds 4 u32 per triangle
+        total += nt
+    assert total == 126048 and fix.c.n_triangles == 124840               # all of them, minus the degenerate ones (mesh_object.rs:128-134)
+
+
 def test_scene_inventory_matches_survey(native, abi):
     host, _ = native
     c = host.LoadedScene(SCENES["cornell"])
