@@ -201,6 +201,8 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         int rc = flatten_mesh(sc, sc->meshes[m], nodes, tris, mesh_ranges[m].first, mesh_ranges[m].second);
         if (rc) return rc;
     }
+    // the BVH walk addresses nodes and triangles with 32-bit byte offsets (node * 32, triangle * 48)
+    if (nodes.size() > (1u << 26) || tris.size() > (1u << 26)) return fail(MI355RT_ERR_INVALID, "more than 2^26 BVH nodes or triangles");
     std::vector<DevPrim> prims(sc->n_primitives);
     for (uint32_t i = 0; i < sc->n_primitives; ++i) {
         const mi355rt_primitive& p = sc->primitives[i];

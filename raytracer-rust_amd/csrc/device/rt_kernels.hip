@@ -339,7 +339,10 @@ DI void mesh_setup(cprim_t pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {
 }
 // Visit m.node (box test, aabb.rs:27-45).  Afterwards either m.node moved on, or a leaf is pending (m.leaf_b > 0).
 DI void mesh_step(const float4* __restrict__ n4, float t_min, MeshTrav& m) {
-    const float4 q0 = n4[2 * (size_t)m.node], q1 = n4[2 * (size_t)m.node + 1];
+    // 32-bit byte offset from the uniform base: the load takes the base from SGPRs instead of a 64-bit per-lane address
+    // (node and triangle counts are validated against 2^26 at upload)
+    const float4* __restrict__ nq = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(n4) + (m.node << 5));
+    const float4 q0 = nq[0], q1 = nq[1];
     const uint32_t a = __float_as_uint(q0.w), b = __float_as_uint(q1.w);
     float tmin = t_min, tmax = m.best_t;
     bool ok = true;
@@ -360,8 +363,8 @@ DI void mesh_step(const float4* __restrict__ n4, float t_min, MeshTrav& m) {
 // Moeller-Trumbore over the pending leaf, bvh.rs:91-138
 DI void mesh_leaf(const float4* __restrict__ t4, float t_min, MeshTrav& m) {
     for (uint32_t k = 0; k < m.leaf_b; ++k) {
-        const size_t ti = 3 * (size_t)(m.leaf_a + k);
-        const float4 r0 = t4[ti], r1 = t4[ti + 1], r2 = t4[ti + 2];
+        const float4* __restrict__ tq = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(t4) + (m.leaf_a + k) * 48u);
+        const float4 r0 = tq[0], r1 = tq[1], r2 = tq[2];
         const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
         f3 hh = cross(m.rd, e2);
         float aa = dot(e1, hh);
