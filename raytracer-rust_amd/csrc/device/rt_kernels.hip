@@ -566,8 +566,9 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const float4 q0, const Hit&
         } else {
             float theta = atanf(sqrtf(theta_arg));
             float phi = 2.0f * PI_F * u2;
-            float st = sinf(theta), ct = cosf(theta);
-            f3 hl = mk(st * cosf(phi), st * sinf(phi), ct);
+            float st, ct, sp, cp;                          // sin_cos(): one argument reduction serves both values
+            sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp);
+            f3 hl = mk(st * cp, st * sp, ct);
             hv = has_nan(hl) ? to_world(mk(0.f, 0.f, 1.f), n) : to_world(hl, n);
         }
         if (has_nan(hv)) return false;
