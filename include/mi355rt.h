@@ -219,6 +219,17 @@ int  mi355rt_context_render_progressive(mi355rt_context* ctx, const mi355rt_opti
                                         void* d_out_packed_rgb, void* d_out_linear_rgb_or_null,
                                         void* hip_stream, mi355rt_stats* stats_or_null);
 
+/* mi355rt_render over several GPUs from ONE host process (the reference's host is a single `main`):
+ * row strips of options.strip_rows rows (0 -> 4) are dealt round-robin over `hip_devices`, each device
+ * renders its strips with the full scene resident and copies them into the caller's image; no
+ * collective is involved.  options.n_parts / part must be left 0 (row_begin / row_end still select a
+ * window, and the outputs then hold only that window).  Bit-identical to the one-device image.  A
+ * device may be listed more than once (testing on a one-GPU machine).                                */
+int  mi355rt_render_multi(const mi355rt_scene* scene, const mi355rt_camera* camera,
+                          const mi355rt_settings* settings, const mi355rt_options* options_or_null,
+                          const int* hip_devices, uint32_t n_devices,
+                          uint32_t* out_packed_rgb, float* out_linear_rgb_or_null, mi355rt_stats* stats_or_null);
+
 /* One-shot progressive render with HOST buffers: mi355rt_render in chunks of `chunk_spp` samples.  After
  * every chunk `on_chunk_or_null(user, samples_done, samples_total, out_packed_rgb)` sees the image so far
  * (what the reference's preview window, src/main.rs:60-75, would show); a non-zero return stops early and

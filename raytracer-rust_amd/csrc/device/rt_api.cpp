@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/mi355rt.h"
@@ -546,6 +547,76 @@ int mi355rt_render(const mi355rt_scene* scene, const mi355rt_camera* camera, con
     mi355rt_context_destroy(ctx);
     g_err = keep;
     return rc;
+}
+
+// One host process, several GPUs (the shape of the reference's own host: a single `main`, src/main.rs:22-89).
+// Row strips are dealt round-robin over `hip_devices` exactly as the one-process-per-GPU path deals them over ranks
+// (options.strip_rows; 0 -> 4); every device gets the full scene, renders its strips on its own host thread and
+// copies them straight into the caller's row-major image -- the exchange step is the device-to-host copy, no
+// collective.  The image is bit-identical to the one-device image (draws are keyed by absolute row / x / sample).
+int mi355rt_render_multi(const mi355rt_scene* scene, const mi355rt_camera* camera, const mi355rt_settings* settings,
+                         const mi355rt_options* opt, const int* hip_devices, uint32_t n_devices,
+                         uint32_t* out_packed, float* out_linear, mi355rt_stats* stats) {
+    if (!out_packed) return fail(MI355RT_ERR_INVALID, "out_packed_rgb is null");
+    if (!hip_devices || n_devices == 0) return fail(MI355RT_ERR_INVALID, "hip_devices is empty");
+    int rc = check_settings(settings); if (rc) return rc;
+    mi355rt_options base{};
+    if (opt) base = *opt; else { base.abi_version = MI355RT_ABI_VERSION; base.rng_mode = MI355RT_RNG_CTR; }
+    if (base.n_parts > 1) return fail(MI355RT_ERR_INVALID, "render_multi deals the strips itself: leave options.n_parts / part at 0");
+    if (base.strip_rows == 0) base.strip_rows = 4;
+    RowSel all; rc = select_rows(*settings, &base, all); if (rc) return rc;       // the rows the caller's buffer holds (row window)
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible == 0) return fail(MI355RT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    for (uint32_t d = 0; d < n_devices; ++d)
+        if (hip_devices[d] < 0 || hip_devices[d] >= visible) return fail(MI355RT_ERR_INVALID, "hip_devices entry out of range");
+    const uint32_t W = settings->width, row0 = all.rows.empty() ? 0u : all.rows.front();
+
+    struct Part { int rc = MI355RT_OK; std::string err; mi355rt_stats st{}; };
+    std::vector<Part> parts(n_devices);
+    auto work = [&](uint32_t d) {
+        Part& me = parts[d];
+        mi355rt_options o = base; o.n_parts = n_devices; o.part = d;
+        RowSel sel;
+        if ((me.rc = select_rows(*settings, &o, sel))) { me.err = g_err; return; }
+        if (sel.rows.empty()) return;
+        const size_t npix = sel.rows.size() * (size_t)W;
+        mi355rt_context* ctx = nullptr; uint32_t* d_packed = nullptr; float* d_linear = nullptr;
+        std::vector<uint32_t> h_packed(npix); std::vector<float> h_linear(out_linear ? npix * 3 : 0);
+        me.rc = mi355rt_context_create(hip_devices[d], &ctx);
+        if (!me.rc) me.rc = mi355rt_context_set_scene(ctx, scene, camera, settings);
+        if (!me.rc && hipMalloc((void**)&d_packed, npix * 4) != hipSuccess) me.rc = fail(MI355RT_ERR_OOM, "hipMalloc(out_packed)");
+        if (!me.rc && out_linear && hipMalloc((void**)&d_linear, npix * 12) != hipSuccess) me.rc = fail(MI355RT_ERR_OOM, "hipMalloc(out_linear)");
+        if (!me.rc) me.rc = mi355rt_context_render(ctx, &o, d_packed, d_linear, nullptr, &me.st);
+        if (!me.rc && hipMemcpy(h_packed.data(), d_packed, npix * 4, hipMemcpyDeviceToHost) != hipSuccess) me.rc = fail(MI355RT_ERR_HIP, "copy back packed");
+        if (!me.rc && out_linear && hipMemcpy(h_linear.data(), d_linear, npix * 12, hipMemcpyDeviceToHost) != hipSuccess) me.rc = fail(MI355RT_ERR_HIP, "copy back linear");
+        if (me.rc) me.err = g_err;
+        else for (size_t j = 0; j < sel.rows.size(); ++j) {                        // de-interleave: local row j is image row sel.rows[j]
+            const size_t dst = (size_t)(sel.rows[j] - row0) * W;
+            std::memcpy(out_packed + dst, h_packed.data() + j * W, (size_t)W * 4);
+            if (out_linear) std::memcpy(out_linear + dst * 3, h_linear.data() + j * W * 3, (size_t)W * 12);
+        }
+        if (d_packed) (void)hipFree(d_packed);
+        if (d_linear) (void)hipFree(d_linear);
+        if (ctx) mi355rt_context_destroy(ctx);
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t d = 1; d < n_devices; ++d) threads.emplace_back(work, d);
+    work(0);
+    for (auto& t : threads) t.join();
+
+    mi355rt_stats total{};
+    for (uint32_t d = 0; d < n_devices; ++d) {
+        if (parts[d].rc) return fail(parts[d].rc, "device " + std::to_string(hip_devices[d]) + ": " + parts[d].err);
+        const mi355rt_stats& s = parts[d].st;
+        total.render_kernel_ms = std::max(total.render_kernel_ms, s.render_kernel_ms);     // the devices run side by side
+        total.resolve_kernel_ms = std::max(total.resolve_kernel_ms, s.resolve_kernel_ms);
+        total.total_ms = std::max(total.total_ms, s.total_ms);
+        total.samples += s.samples; total.rays += s.rays; total.rows_rendered += s.rows_rendered; total.bands += s.bands;
+        total.grid_blocks = std::max(total.grid_blocks, s.grid_blocks); total.block_threads = s.block_threads ? s.block_threads : total.block_threads;
+        total.kernel_vgprs = s.kernel_vgprs ? s.kernel_vgprs : total.kernel_vgprs; total.kernel_sgprs = s.kernel_sgprs ? s.kernel_sgprs : total.kernel_sgprs;
+    }
+    if (stats) *stats = total;
+    return MI355RT_OK;
 }
 
 // Host-buffer progressive render: what a preview window (src/main.rs:60-75) would be fed from.

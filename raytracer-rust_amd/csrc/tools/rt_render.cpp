@@ -3,7 +3,8 @@
 // save the PNG (main.rs:58).  The minifb preview window (main.rs:60-75) becomes --chunk: a PNG that refines.
 //
 //   rt_render <scene.json> [-o out.png] [--width W] [--height H] [--spp N] [--max-depth D]
-//             [--rng ctr|ref] [--seed S] [--skip-unknown] [--chunk N] [--pfm out.pfm]
+//             [--rng ctr|ref] [--seed S] [--skip-unknown] [--chunk N] [--pfm out.pfm] [--gpus N]
+// --gpus N deals row strips over HIP devices 0..N-1 from this one process (mi355rt_render_multi).
 // --chunk N renders N samples per pixel at a time and rewrites the PNG after every chunk (a preview that refines).
 #include <chrono>
 #include <cstdio>
@@ -15,9 +16,9 @@
 #include "../../../include/mi355rt.h"
 
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s <scene.json> [-o out.png] [--width W] [--height H] [--spp N] [--max-depth D] [--rng ctr|ref] [--seed S] [--skip-unknown] [--chunk N] [--pfm out.pfm]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <scene.json> [-o out.png] [--width W] [--height H] [--spp N] [--max-depth D] [--rng ctr|ref] [--seed S] [--skip-unknown] [--chunk N] [--pfm out.pfm] [--gpus N]\n", argv[0]); return 2; }
     std::string scene_path = argv[1], out_path = "render_pt.png", pfm_path;
-    mi355rt_load_overrides ov{}; mi355rt_options opt{}; uint32_t chunk = 0;
+    mi355rt_load_overrides ov{}; mi355rt_options opt{}; uint32_t chunk = 0, gpus = 1;
     opt.abi_version = MI355RT_ABI_VERSION; opt.rng_mode = MI355RT_RNG_CTR; opt.strip_rows = 1; opt.n_parts = 1;
     for (int i = 2; i < argc; ++i) {
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
@@ -31,6 +32,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--skip-unknown")) ov.skip_unknown_primitives = 1;
         else if (!std::strcmp(argv[i], "--chunk")) chunk = (uint32_t)std::atoi(next());
         else if (!std::strcmp(argv[i], "--pfm")) pfm_path = next();
+        else if (!std::strcmp(argv[i], "--gpus")) gpus = (uint32_t)std::atoi(next());
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     std::printf("Attempting to load scene from: %s\n", scene_path.c_str());
@@ -53,7 +55,11 @@ int main(int argc, char** argv) {
         if (done < total) (void)mi355rt_write_png(p->path, packed, p->w, p->h);       // the final image is written below
         return 0;
     };
-    int rc = chunk ? mi355rt_render_progressive(sc, mi355rt_loaded_scene_camera(ls), st, &opt, chunk, on_chunk, &pv, buffer.data(), lin, &stats)
+    std::vector<int> devices;
+    for (uint32_t d = 0; d < gpus; ++d) devices.push_back((int)d);
+    if (gpus > 1) { opt.strip_rows = 4; opt.n_parts = 0; }
+    int rc = gpus > 1 ? mi355rt_render_multi(sc, mi355rt_loaded_scene_camera(ls), st, &opt, devices.data(), gpus, buffer.data(), lin, &stats)
+           : chunk ? mi355rt_render_progressive(sc, mi355rt_loaded_scene_camera(ls), st, &opt, chunk, on_chunk, &pv, buffer.data(), lin, &stats)
                    : mi355rt_render(sc, mi355rt_loaded_scene_camera(ls), st, &opt, buffer.data(), lin, &stats);   // <- src/main.rs:57
     if (rc != MI355RT_OK) { std::fprintf(stderr, "render failed (%d): %s\n", rc, mi355rt_last_error()); mi355rt_scene_free(ls); return 1; }
     std::printf("Rendered in %.3f seconds (kernels %.3f ms path tracing + %.3f ms resolve; %.1f Msamples/s, %.2f rays/sample)\n",

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import abi, build
 
-EXPORTS = ["mi355rt_render", "mi355rt_render_progressive", "mi355rt_context_create", "mi355rt_context_destroy", "mi355rt_context_set_scene",
+EXPORTS = ["mi355rt_render", "mi355rt_render_multi", "mi355rt_render_progressive", "mi355rt_context_create", "mi355rt_context_destroy", "mi355rt_context_set_scene",
            "mi355rt_rows_selected", "mi355rt_context_render", "mi355rt_context_render_progressive", "mi355rt_context_set_timing", "mi355rt_context_read_timing",
            "mi355rt_last_error", "mi355rt_abi_version"]
 
@@ -31,6 +31,9 @@ def lib():
         L.mi355rt_render.restype = C.c_int
         L.mi355rt_render.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(abi.Settings),
                                      C.POINTER(abi.Options), C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
+        L.mi355rt_render_multi.restype = C.c_int
+        L.mi355rt_render_multi.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(abi.Settings), C.POINTER(abi.Options),
+                                           C.POINTER(C.c_int), C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
         L.mi355rt_context_create.restype = C.c_int
         L.mi355rt_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.mi355rt_context_destroy.argtypes = [C.c_void_p]
@@ -78,6 +81,20 @@ def render(scene, camera, settings, options=None, want_linear=True, want_stats=T
                                 C.byref(options) if options is not None else None,
                                 packed.ctypes.data, linear.ctypes.data if want_linear else None,
                                 C.byref(stats) if want_stats else None), "mi355rt_render")
+    return packed, linear, stats
+
+
+def render_multi(scene, camera, settings, devices, options=None, want_linear=True):
+    """mi355rt_render_multi: one process, the listed HIP devices (a device may repeat).  Same returns as render()."""
+    sc = getattr(scene, "c", scene)
+    rows = len(abi.rows_selected(settings.height, options)) if options is not None else settings.height
+    packed = np.zeros((rows, settings.width), np.uint32)
+    linear = np.zeros((rows, settings.width, 3), np.float32) if want_linear else None
+    stats = abi.Stats()
+    devs = (C.c_int * len(devices))(*devices)
+    _check(lib().mi355rt_render_multi(C.byref(sc), C.byref(camera), C.byref(settings), C.byref(options) if options is not None else None,
+                                      devs, len(devices), packed.ctypes.data, linear.ctypes.data if want_linear else None, C.byref(stats)),
+           "mi355rt_render_multi")
     return packed, linear, stats
 
 
