@@ -479,6 +479,13 @@ int mi355rt_context_render_progressive(mi355rt_context* ctx, const mi355rt_optio
     return render_samples(ctx, opt, sample_begin, sample_end, d_accum, d_out_packed, d_out_linear, hip_stream, stats);
 }
 
+// Diagnostic hook (not part of the public header): which counter-mode kernel set_scene selected (KERNEL_* in rt_device.h).
+int mi355rt_debug_kernel_variant(mi355rt_context* ctx, uint32_t* out) {
+    if (!ctx || !out || !ctx->have_scene) return fail(MI355RT_ERR_INVALID, "context has no scene");
+    *out = ctx->variant;
+    return MI355RT_OK;
+}
+
 // Diagnostic hook (not part of the public header): the 16 raw device counters of the last render.
 int mi355rt_debug_read_counters(mi355rt_context* ctx, unsigned long long* out16) {
     if (!ctx || !out16 || !ctx->stats.p) return fail(MI355RT_ERR_INVALID, "no counters");

@@ -817,13 +817,13 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
 }
 
 // Register budget per kernel, as waves per SIMD (A/B: tools/ab.py).  The lockstep kernel is VALU-issue bound
-// and gains from 6 waves/SIMD even with a few spills; the state-machine kernel keeps its hot BVH state in
+// and gains from 7 waves/SIMD (72 VGPRs) even with a few spills; the state-machine kernel keeps its hot BVH state in
 // registers and loses when capped.
 #ifndef MI355RT_TRAV_BIAS
 #define MI355RT_TRAV_BIAS 2
 #endif
 #ifndef MI355RT_OCC_LOCKSTEP
-#define MI355RT_OCC_LOCKSTEP 6
+#define MI355RT_OCC_LOCKSTEP 7                               // veach-mis: 4 -> 6.46 ms, 5 -> 6.03, 6 -> 5.79, 7 -> 5.73 (64 spp)
 #endif
 #if MI355RT_OCC_LOCKSTEP > 0
 #define MI355RT_OCC_LS __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_LOCKSTEP, MI355RT_OCC_LOCKSTEP)))
@@ -893,12 +893,12 @@ DI void render_ctr_lockstep(const RenderParams& P) {
 }
 
 // Entry points: one body, instantiated per scene class so that each gets its own register budget.
-//   k_render_ctr_nomesh  any materials, no mesh in the list            (veach-mis)                6 waves/SIMD
+//   k_render_ctr_nomesh  any materials, no mesh in the list            (veach-mis)                7 waves/SIMD
 //   k_render_ctr_simple  Lambertian/Emissive/Null only, no mesh        (cornell: -3 % vs nomesh)   7 waves/SIMD
 //   k_render_ctr_mesh    lockstep with the per-lane BVH walk inlined   (A/B reference for the state machine)
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_nomesh(const RenderParams P) { render_ctr_lockstep<false, false>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_simple(const RenderParams P) { render_ctr_lockstep<false, true>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_mesh(const RenderParams P) { render_ctr_lockstep<true, false>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_render_ctr_mesh(const RenderParams P) { render_ctr_lockstep<true, false>(P); }
 
 // ===================================================================================================
 // k_render_ctr_sm -- the same path tracer as a wave-scheduled state machine, for scenes with meshes.

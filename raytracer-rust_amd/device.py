@@ -137,6 +137,12 @@ class Context:
                                                         C.byref(stats) if stats is not None else None), "mi355rt_context_render_progressive")
         return stats
 
+    def kernel_variant(self):
+        """Diagnostic: the counter-mode kernel chosen for the resident scene (0 lockstep, 1 lockstep+mesh, 2 state machine, 3 lockstep simple)."""
+        v = C.c_uint32()
+        _check(lib().mi355rt_debug_kernel_variant(self._h, C.byref(v)), "mi355rt_debug_kernel_variant")
+        return v.value
+
     def set_timing(self, enable=True):
         _check(lib().mi355rt_context_set_timing(self._h, 1 if enable else 0), "mi355rt_context_set_timing")
 

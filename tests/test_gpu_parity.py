@@ -118,25 +118,38 @@ def test_state_machine_equals_lockstep_walk(name, native, oracle_mod, abi, monke
 
 def test_simple_material_kernel_equals_general(native, oracle_mod, abi, monkeypatch):
     """cornell has only Lambertian / Emissive materials, so set_scene picks the instantiation with the other BSDFs
-    compiled out (fewer registers, 7 waves/SIMD).  It must be bit-identical to the general lockstep kernel and to
-    the oracle, and must NOT be picked (nor be forceable) for a scene that has any other material."""
+    compiled out.  It must be bit-identical to the general lockstep kernel and to the oracle, and must NOT be
+    picked (nor be forceable) for a scene that has any other material."""
+    import torch
     host, device = native
+
+    def run(sc):
+        ctx = device.Context(0)
+        ctx.set_scene(sc, sc.camera, sc.settings)
+        n = sc.settings.width * sc.settings.height
+        packed = torch.zeros(n, dtype=torch.int32, device="cuda")
+        linear = torch.zeros(n * 3, dtype=torch.float32, device="cuda")
+        st = ctx.render(packed.data_ptr(), linear.data_ptr(), abi.Options.make(), want_stats=True)
+        v = ctx.kernel_variant()
+        ctx.close()
+        return v, packed.cpu().numpy().view(np.uint32), linear.cpu().numpy(), st.rays
+
     sc = load_for_both("cornell", oracle_mod, host, width=80, height=48, spp=9, max_depth=12)
     monkeypatch.delenv("MI355RT_KERNEL", raising=False)
-    gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make())
+    v, gp, gl, rays = run(sc)
     monkeypatch.setenv("MI355RT_KERNEL", "0")
-    gp0, gl0, st0 = device.render(sc, sc.camera, sc.settings, abi.Options.make())
-    assert st.kernel_vgprs < st0.kernel_vgprs, "the simple-materials instantiation was not selected for cornell"
-    assert np.array_equal(gl.view(np.uint32), gl0.view(np.uint32)) and np.array_equal(gp, gp0) and st.rays == st0.rays
+    v0, gp0, gl0, rays0 = run(sc)
+    assert (v, v0) == (3, 0), "the simple-materials instantiation was not selected for cornell"
+    assert np.array_equal(gl.view(np.uint32), gl0.view(np.uint32)) and np.array_equal(gp, gp0) and rays == rays0
     op, ol, cnt = oracle_mod.render(sc, sc.camera, sc.settings, abi.Options.make())
-    assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and cnt.rays == st.rays
+    assert np.array_equal(gl.view(np.uint32), ol.reshape(-1).view(np.uint32)) and cnt.rays == rays
 
     sv = load_for_both("veach", oracle_mod, host, width=80, height=48, spp=4, max_depth=8)
     monkeypatch.delenv("MI355RT_KERNEL", raising=False)
-    _, vl, vst = device.render(sv, sv.camera, sv.settings, abi.Options.make())
+    vv, _, vl, _ = run(sv)
     monkeypatch.setenv("MI355RT_KERNEL", "3")             # refused: the scene has RoughConductor materials
-    _, vl3, vst3 = device.render(sv, sv.camera, sv.settings, abi.Options.make())
-    assert vst.kernel_vgprs == st0.kernel_vgprs == vst3.kernel_vgprs
+    vv3, _, vl3, _ = run(sv)
+    assert (vv, vv3) == (0, 0)
     assert np.array_equal(vl.view(np.uint32), vl3.view(np.uint32))
 
 
