@@ -1,0 +1,29 @@
+"""Long parity soak: many random scenes (every primitive / material kind), HIP path vs oracle, both RNG modes.
+usage: python tools/fuzz_soak.py [first_seed] [n_seeds]   (run on a GPU box; prints one line per seed and a summary)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from conftest import pkg
+import oracle
+from fuzz_scenes import random_scene
+import torch; torch.zeros(1, device="cuda")
+abi, host, device = pkg("abi"), pkg("host"), pkg("device")
+oracle.build()
+first, n = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = 0; t0 = time.time()
+for seed in range(first, first + n):
+    shapes = [dict(), dict(n_prims=5, mesh_tris=400), dict(n_prims=30, mesh_tris=10), dict(n_prims=8, only_kinds=[4, 3, 4, 2], mesh_tris=150)]
+    kw = shapes[seed % len(shapes)]
+    sc = random_scene(abi, host, seed, exact_only=True, **kw)
+    st = abi.Settings(40 + seed % 37, 30 + seed % 23, 3 + seed % 6, 2 + seed % 11)
+    line = []
+    for mode in (0, 1):
+        opt = abi.Options.make(rng_mode=mode, seed=seed * 7919 if mode == 0 else 0)
+        gp, gl, gs = device.render(sc, sc.camera, st, opt)
+        op, ol, cnt = oracle.render(sc, sc.camera, st, opt)
+        ok = gs.rays == cnt.rays and np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op)
+        bad += 0 if ok else 1
+        line.append("ok" if ok else f"MISMATCH({int((gl != ol).any(-1).sum())} px, rays {gs.rays} vs {cnt.rays})")
+    print(f"seed {seed} {st.width}x{st.height}x{st.samples_per_pixel} d{st.max_depth} {kw}: ctr {line[0]}  ref {line[1]}", flush=True)
+print(f"{n} scenes x 2 modes: {bad} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
