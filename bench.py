@@ -39,6 +39,7 @@ WORKLOADS = {
 }
 REC_BYTES = {0: 16, 1: 24, 2: 64, 3: 128, 4: 128}     # sphere, plane, quad, cube, mesh header
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_SIMDS, VALU_CLOCK_HZ, VALU_CYCLES_PER_WAVE64_INST = 1024, 2.4e9, 2     # 256 CUs x 4 SIMDs; 157.3 TFLOP/s f32 = 1024 x 32 lanes x 2 x 2.4 GHz
 
 
 def main():
@@ -145,12 +146,22 @@ def main():
         ms_per_launch = k_render_ms / max(launches, 1)
         achieved = bytes_per_sample * local_samples / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
         traffic = None
+        valu = None                              # the unit that really binds: f32 VALU issue slots (PMC instruction count / live kernel time)
         pmc = os.path.join(ROOT, "profiles", "pmc_hbm_bytes.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("k_render_ctr_hbm_bytes_per_launch")
+                rec_pmc = json.load(open(pmc)).get(args.workload, {})
+                traffic = rec_pmc.get("k_render_ctr_hbm_bytes_per_launch")
                 if traffic is not None:          # measured on the whole image in one launch; a rank renders local_samples of it
                     traffic = int(traffic * local_samples / total_samples)
+                insts = rec_pmc.get("k_render_ctr_valu_insts_per_launch")
+                if insts is not None and ms_per_launch > 0:
+                    peak = VALU_SIMDS * VALU_CLOCK_HZ / VALU_CYCLES_PER_WAVE64_INST
+                    rate = insts * local_samples / total_samples / (ms_per_launch * 1e-3)
+                    valu = {"wave_insts_per_launch": int(insts * local_samples / total_samples), "achieved_ginst_s": round(rate / 1e9, 1),
+                            "peak_ginst_s": round(peak / 1e9, 1), "frac": round(rate / peak, 4),
+                            "lane_utilisation": rec_pmc.get("k_render_ctr_valu_lane_utilisation"),
+                            "note": "SQ_INSTS_VALU (PMC, profiles/) / live kernel time vs 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
             except Exception:
                 traffic = None
         result = {
@@ -166,7 +177,8 @@ def main():
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1), "rays_per_sample": round(rays_per_sample, 4),
                          "kernel_ms_per_launch": round(ms_per_launch, 4), "resolve_ms_per_launch": round(k_resolve_ms / max(launches, 1), 4),
                          "launches_timed": launches, "samples_per_launch": local_samples,
-                         "note": "scene records are SGPR/L2 resident, so algorithmic bytes never reach HBM; the binding unit is the f32 VALU"},
+                         "valu": valu,
+                         "note": "scene records are SGPR/L2 resident, so algorithmic bytes never reach HBM; the binding unit is the f32 VALU (see valu)"},
             "cpu_baseline": cpu_baseline,
             **({"rehearsal": "all ranks on cuda:0 over gloo -- plumbing check only, NOT a measurement"} if rehearse else {}),
             "kernel": {"vgprs": st.kernel_vgprs, "grid_blocks": st.grid_blocks, "block_threads": st.block_threads, "bands": st.bands},
