@@ -275,8 +275,18 @@ DI f3 xform_normal(cprim_t pr, f3 n) {               // (w2o.transpose() * (n, 0
 }
 DI float glam_signum(float v) { if (v != v) return v; return copysignf(1.0f, v); }
 
-// objects/cube.rs:59-158
-DI bool hit_cube(cprim_t pr, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h) {
+// objects/cube.rs:59-158.  The face normal (cube.rs:105-143) is DEFERRED: the list walk only needs t and the position
+// to go on, and of all the cube hits a ray collects only the closest one is ever shaded.  A hit therefore leaves the
+// object-space point in h.n and HIT_PENDING_CUBE | list index in h.mat_ff; finish_cube_hit() turns that into the
+// normal / face / material once per ray, after the list (hit_scene) or when the lane reaches SHADE (state machine).
+constexpr uint32_t HIT_PENDING_CUBE = 0x40000000u;
+DI uint32_t cube_axis(f3 po) {                                                          // cube.rs:112-133 as selects
+    const float ax = fabsf(po.x), ay = fabsf(po.y), az = fabsf(po.z);
+    const float tol = 1e-4f;
+    return (fabsf(ax - 0.5f) < tol) ? 0u : (fabsf(ay - 0.5f) < tol) ? 1u : (fabsf(az - 0.5f) < tol) ? 2u
+         : (ax > ay && ax > az) ? 0u : (ay > az) ? 1u : 2u;
+}
+DI bool hit_cube(cprim_t pr, uint32_t list_index, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h) {
     f3 ro = xform_w2o_point(pr, ro_w);
     f3 rd = xform_w2o_dir(pr, rd_w);
     float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
@@ -289,32 +299,43 @@ DI bool hit_cube(cprim_t pr, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h)
     const bool candidate = !(t_exit < t_enter || t_exit <= 0.0f) && !(t_hit >= t_max || t_hit <= t_min || t_hit < EPS);   // cube.rs:90-103, one branch
     if (!candidate) return false;
     f3 po = ro + rd * t_hit;
-    // cube.rs:105-134: the object-space normal is +-e_axis, normalize_or_zero() of such a vector is the vector
-    // itself (1/sqrt(1) == 1) unless the chosen coordinate is NaN (then it is zero), and the world normal
-    // normalized(w2o^T * (n, 0)) therefore takes one of 6 values per cube, which the host precomputed with the same
-    // f32 operations (DevPrim.d[34..51], rt_api.cpp cube_normal_table).
-    float ax = fabsf(po.x), ay = fabsf(po.y), az = fabsf(po.z);
-    const float tol = 1e-4f;
-    const uint32_t axis = (fabsf(ax - 0.5f) < tol) ? 0u : (fabsf(ay - 0.5f) < tol) ? 1u : (fabsf(az - 0.5f) < tol) ? 2u
-                        : (ax > ay && ax > az) ? 0u : (ay > az) ? 1u : 2u;                    // cube.rs:112-133 as selects
-    const float c = (axis == 0u) ? po.x : ((axis == 1u) ? po.y : po.z);
-    f3 nw;
-    if (c != c) {                                         // NaN coordinate: signum -> NaN -> normalize_or_zero -> 0
-        nw = normalized(xform_normal(pr, mk(0.f, 0.f, 0.f)));
-    } else {
-        const uint32_t code = 2u * axis + (__float_as_uint(c) >> 31);     // glam signum: sign bit decides, also for +-0
-        const auto* t = pr->d + 34;
-        nw.x = code == 0u ? t[0] : code == 1u ? t[3] : code == 2u ? t[6] : code == 3u ? t[9] : code == 4u ? t[12] : t[15];
-        nw.y = code == 0u ? t[1] : code == 1u ? t[4] : code == 2u ? t[7] : code == 3u ? t[10] : code == 4u ? t[13] : t[16];
-        nw.z = code == 0u ? t[2] : code == 1u ? t[5] : code == 2u ? t[8] : code == 3u ? t[11] : code == 4u ? t[14] : t[17];
-    }
     f3 pw = xform_o2w_point(pr, po);
     const float t_world = dot(pw - ro_w, rd_w);                                             // cube.rs:145-153: the same dot product twice
     if ((t_world < 0.0f) || (t_world < t_min || t_world > t_max)) return false;
     h.t = t_world; h.p = pw;
-    set_face(h, rd_w, nw, pr->material);
+    if (has_nan(po)) {
+        // a NaN coordinate can make signum NaN -> normalize_or_zero -> the zero vector (cube.rs:134): settle it here
+        const uint32_t axis = cube_axis(po);
+        const float c = (axis == 0u) ? po.x : ((axis == 1u) ? po.y : po.z);
+        f3 nw;
+        if (c != c) nw = normalized(xform_normal(pr, mk(0.f, 0.f, 0.f)));
+        else {
+            const uint32_t code = 2u * axis + (__float_as_uint(c) >> 31);
+            const auto* t = pr->d + 34;
+            nw.x = code == 0u ? t[0] : code == 1u ? t[3] : code == 2u ? t[6] : code == 3u ? t[9] : code == 4u ? t[12] : t[15];
+            nw.y = code == 0u ? t[1] : code == 1u ? t[4] : code == 2u ? t[7] : code == 3u ? t[10] : code == 4u ? t[13] : t[16];
+            nw.z = code == 0u ? t[2] : code == 1u ? t[5] : code == 2u ? t[8] : code == 3u ? t[11] : code == 4u ? t[14] : t[17];
+        }
+        set_face(h, rd_w, nw, pr->material);
+    } else {
+        h.n = po; h.mat_ff = HIT_PENDING_CUBE | list_index;
+    }
     return true;
 }
+// The deferred half of a cube hit.  The object-space normal is +-e_axis, normalize_or_zero() of such a vector is the vector
+// itself (1/sqrt(1) == 1), and the world normal normalized(w2o^T * (n, 0)) therefore takes one of 6 values per cube, which
+// the host precomputed with the same f32 operations (DevPrim.d[34..51], rt_api.cpp cube_normal_table).  Per-lane record:
+// lanes of one wave may have hit different cubes.
+DI void finish_cube_hit(const DevPrim* __restrict__ prims, Hit& h, f3 rd_w) {
+    const DevPrim* __restrict__ pr = prims + (h.mat_ff & (HIT_PENDING_CUBE - 1u));
+    const f3 po = h.n;
+    const uint32_t axis = cube_axis(po);
+    const float c = (axis == 0u) ? po.x : ((axis == 1u) ? po.y : po.z);
+    const uint32_t code = 2u * axis + (__float_as_uint(c) >> 31);                       // glam signum: the sign bit decides, also for +-0
+    const float* __restrict__ t = pr->d + 34u + 3u * code;
+    set_face(h, rd_w, mk(t[0], t[1], t[2]), pr->material);
+}
+DI bool hit_pending(const Hit& h) { return (h.mat_ff & 0xC0000000u) == HIT_PENDING_CUBE; }   // bit 31 is front_face of a finished record
 
 // mesh/mesh_object.rs:263-329 + acceleration/bvh.rs:78-170 + acceleration/aabb.rs:27-45.
 // Threaded pre-order walk; `best_t` plays the role of the recursion's shrinking t_max.  The walk is split
@@ -419,11 +440,12 @@ DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
             case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ro, rd, EPS, closest, h); break;
             case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ro, rd, EPS, closest, h); break;
             case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ro, rd, EPS, closest, h); break;
-            case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, ro, rd, EPS, closest, h); break;
+            case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, i, ro, rd, EPS, closest, h); break;
             default:                  if (HAS_MESH) hit = hit_mesh(pr, nodes, tris, ro, rd, EPS, closest, h); break;
         }
         if (hit) { closest = h.t; best = h; any = true; }
     }
+    if (any && hit_pending(best)) finish_cube_hit((const DevPrim*)prims, best, rd);
     return any;
 }
 
@@ -989,7 +1011,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
                         case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ps.ro, ps.rd, EPS, closest, h); break;
                         case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ps.ro, ps.rd, EPS, closest, h); break;
                         case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ps.ro, ps.rd, EPS, closest, h); break;
-                        case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, ps.ro, ps.rd, EPS, closest, h); break;
+                        case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, i, ps.ro, ps.rd, EPS, closest, h); break;
                         default:
                             if (!walk_done) {
                                 // Most rays leave a mesh within a few box tests (they miss its root or upper boxes):
@@ -1016,6 +1038,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
         }
         // ---- SHADE + regeneration (lanes in TOP / TRAV are left untouched) ----
         bool live = (state == ST_SHADE);
+        if (live && any_hit && hit_pending(best)) finish_cube_hit(P.prims, best, ps.rd);   // the deferred cube normal, once per ray
         const bool part = live || state == ST_IDLE;
         MI355RT_COUNT(3, __ballot(part));
         shade_and_regenerate<false>(P, wc, lane, live, part, any_hit, best, ps, n_paths, n_rays, prof);
