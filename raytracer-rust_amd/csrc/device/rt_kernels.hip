@@ -1059,47 +1059,41 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
 }
 
 // ===================================================================================================
-// k_resolve -- ordered per-pixel sum, 1/spp, sqrt gamma, pack (renderer.rs:100-120)
+// k_resolve -- ordered per-pixel sum, 1/spp, sqrt gamma, pack (renderer.rs:100-120), without LDS.
+// One pixel's samples are contiguous in HBM (spp * 16 B apart from the next pixel's) and must be added in sample order.
+// A 16-lane DPP row owns one pixel; lane s of the row loads sample
+// c + s (64 lanes = 4 pixels x 16 samples = four fully coalesced 256-byte segments), and the sequential sum
+// ((acc + x0) + x1) + ... + x15 runs ALONG the row: T = row_shr:1(T) + x, fifteen times.  Lane k's value is final after
+// step k and every later step recomputes exactly the same sum (its left neighbour no longer changes), so no select is
+// needed; lane 0 reads 0 from outside the row (bound_ctrl) and 0 + (acc + x0) is exact (a running sum that started at
+// +0 is never -0).  Samples past spp enter as +0, which leaves a sum unchanged.  No LDS, 14 VGPRs: enough waves in
+// flight to keep the HBM read stream busy (6.4 TB/s; the LDS-transpose version it replaces reached 3.3).
 // ===================================================================================================
-// A lane owns a pixel and must add that pixel's samples in order, but one pixel's samples are contiguous in HBM
-// (spp * 16 B apart from the next pixel's).  Each wave therefore moves 64 pixels x 16 samples at a time through
-// LDS: 16 fully coalesced loads (16 lanes x 16 B = 256 contiguous bytes per pixel, 4 pixels per instruction),
-// written to a [pixel][17] float4 image (one slot of padding: lane l reads slot 17*l + k, conflict-free for
-// ds_read_b128), then every lane reads back its own pixel's 16 samples and adds them in sample order.
-// Each wave owns its LDS region, so no workgroup barrier is needed.
-constexpr uint32_t RES_CHUNK = 16, RES_PITCH = 17;
+DI float dpp_row_shr1_zero(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true)); }
+DI float dpp_row_ror1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, true)); }
 __global__ void __launch_bounds__(256) k_resolve(const ResolveParams P) {
-    __shared__ float4 stage[4][64 * RES_PITCH];                  // 4 waves x 17 408 B
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t p0 = (blockIdx.x * 4u + wave) * 64u;          // first pixel of this wave
-    if (p0 >= P.band_pixels) return;                             // wave-uniform
-    const uint32_t p = p0 + lane;
-    const float4* __restrict__ rad = reinterpret_cast<const float4*>(P.radiance);
-    float4* __restrict__ mine = stage[wave];
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    f3 acc = mk(0.f, 0.f, 0.f);
-    float4* __restrict__ accum = reinterpret_cast<float4*>(P.accum);
-    if (accum && P.accum_load && p < P.band_pixels) { const float4 a = accum[(size_t)P.band_pixel0 + p]; acc = mk(a.x, a.y, a.z); }   // the sum goes on where it stopped
-    const uint32_t sub_pix = lane >> 4, sub_s = lane & 15u;
-    for (uint32_t c = 0; c < P.spp; c += RES_CHUNK) {
-        const uint32_t s = c + sub_s;
-#pragma unroll
-        for (uint32_t i = 0; i < 16; ++i) {
-            const uint32_t pl = 4u * i + sub_pix;                // pixel within the wave's 64
-            if (p0 + pl < P.band_pixels && s < P.spp) {
-                const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(rad + (size_t)(p0 + pl) * P.spp + s));
-                mine[pl * RES_PITCH + sub_s] = make_float4(v.x, v.y, v.z, v.w);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS writes of this wave before its own reads
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n = min(RES_CHUNK, P.spp - c);
-        for (uint32_t k = 0; k < n; ++k) { const float4 v = mine[lane * RES_PITCH + k]; acc = acc + mk(v.x, v.y, v.z); }   // renderer.rs:100
-        __builtin_amdgcn_wave_barrier();                         // reads done before the next chunk overwrites
-    }
-    if (p >= P.band_pixels) return;
-    const f3 pixel = acc * P.inv_spp;                            // renderer.rs:103
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t s = lane & 15u;
+    const uint32_t p = wave * 4u + (lane >> 4);                  // this row's pixel within the band
+    const bool valid = p < P.band_pixels;
     const size_t o = (size_t)P.band_pixel0 + p;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f* __restrict__ rad = reinterpret_cast<const v4f*>(P.radiance) + (size_t)(valid ? p : 0u) * P.spp;
+    float4* __restrict__ accum = reinterpret_cast<float4*>(P.accum);
+    f3 acc = mk(0.f, 0.f, 0.f);                                  // meaningful in lane 0 of the row
+    if (accum && P.accum_load && valid) { const float4 a = accum[o]; acc = mk(a.x, a.y, a.z); }
+    for (uint32_t c = 0; c < P.spp; c += 16u) {
+        f3 x = mk(0.f, 0.f, 0.f);
+        if (valid && c + s < P.spp) { const v4f v = __builtin_nontemporal_load(rad + c + s); x = mk(v.x, v.y, v.z); }
+        if (s == 0u) x = acc + x;                                 // renderer.rs:100 goes on where the previous 16 samples stopped
+        f3 t = x;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) t = mk(dpp_row_shr1_zero(t.x) + x.x, dpp_row_shr1_zero(t.y) + x.y, dpp_row_shr1_zero(t.z) + x.z);
+        acc = mk(dpp_row_ror1(t.x), dpp_row_ror1(t.y), dpp_row_ror1(t.z));   // lane 0 <- lane 15: the sum so far
+    }
+    if (!valid || s != 0u) return;
+    const f3 pixel = acc * P.inv_spp;                            // renderer.rs:103
     if (accum) accum[o] = make_float4(acc.x, acc.y, acc.z, 0.0f);
     if (P.out_linear) { P.out_linear[3 * o] = pixel.x; P.out_linear[3 * o + 1] = pixel.y; P.out_linear[3 * o + 2] = pixel.z; }
     P.out_packed[o] = color_to_u32(sqrt3(pixel));                // renderer.rs:112-120
@@ -1166,7 +1160,7 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
     return (int)hipGetLastError();
 }
 int launch_resolve(const ResolveParams& p, void* stream) {
-    const uint32_t blocks = (p.band_pixels + 255u) / 256u;       // 4 waves x 64 pixels per block
+    const uint32_t blocks = (p.band_pixels + 15u) / 16u;         // 4 waves x 4 pixels per block
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
