@@ -155,6 +155,13 @@ enum {
                             whole row (src/renderer.rs:91). One lane per row -- validation only.   */
 };
 
+/* options.flags */
+/* Opt-in fix, never the default (it changes the image): the BVH slab test misses a box only when t_max < t_min.
+ * The reference tests t_max <= t_min (src/acceleration/aabb.rs:41), so boxes of zero thickness -- every leaf of
+ * axis-aligned flat geometry -- are never entered and their triangles are invisible.
+ * Counter-mode RNG only. */
+#define MI355RT_FLAG_FIXED_AABB 1u
+
 typedef struct mi355rt_options {
     uint32_t abi_version;     /* MI355RT_ABI_VERSION                                               */
     uint32_t rng_mode;        /* MI355RT_RNG_*                                                     */
@@ -165,7 +172,7 @@ typedef struct mi355rt_options {
      * {0, height, 1, 1, 0} renders the whole image.  row_end == 0 means `height`.               */
     uint32_t row_begin, row_end;
     uint32_t strip_rows, n_parts, part;
-    uint32_t _pad;
+    uint32_t flags;             /* MI355RT_FLAG_*; 0 reproduces the reference                      */
     uint64_t workspace_bytes; /* cap for the per-sample radiance workspace in HBM; 0 = default (32 GiB,
                                  of which only width*rows*spp*16 bytes are allocated)             */
 } mi355rt_options;

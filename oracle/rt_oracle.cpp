@@ -278,6 +278,8 @@ struct Counters {
 // ------------------------------------------------------------------------------------------------
 // acceleration/aabb.rs, acceleration/bvh.rs, mesh/triangle.rs
 // ------------------------------------------------------------------------------------------------
+// MI355RT_FLAG_FIXED_AABB (opt-in, not the reference): set for the duration of one oracle_render call.
+static bool g_fixed_aabb = false;
 struct Aabb {
     V3 min, max;
     static Aabb empty() {                                                            // aabb.rs:11-16
@@ -296,7 +298,7 @@ struct Aabb {
             if (inv_d < 0.0f) std::swap(t0, t1);
             t_min = std::fmax(t_min, t0);      // f32::max ignores NaN, like fmaxf
             t_max = std::fmin(t_max, t1);
-            if (t_max <= t_min) return false;  // zero-thickness boxes never hit
+            if (g_fixed_aabb ? (t_max < t_min) : (t_max <= t_min)) return false;  // reference: zero-thickness boxes never hit
         }
         return true;
     }
@@ -880,6 +882,7 @@ int oracle_render(const mi355rt_scene* scene_in, const mi355rt_camera* cam, cons
     const uint32_t rng_mode = opt ? opt->rng_mode : MI355RT_RNG_CTR;
     const uint64_t seed = opt ? opt->seed : 0;
     const bool tail = (fold < 0) ? (rng_mode == MI355RT_RNG_REF) : (fold == 0);
+    g_fixed_aabb = opt && (opt->flags & MI355RT_FLAG_FIXED_AABB) != 0u;               // workers are started below, joined before returning
     const uint32_t W = st->width, H = st->height, spp = st->samples_per_pixel, max_depth = st->max_depth;
     if (W == 0 || H == 0 || spp == 0) return MI355RT_ERR_INVALID;
     const float inv_spp = 1.0f / (float)spp;                                          // renderer.rs:85
@@ -939,6 +942,7 @@ int oracle_render(const mi355rt_scene* scene_in, const mi355rt_camera* cam, cons
         counters_out->depth_exhausted = tot.depth_exhausted;
         counters_out->seconds = std::chrono::duration<double>(t_end - t_begin).count();
     }
+    g_fixed_aabb = false;
     return MI355RT_OK;
 }
 

@@ -13,6 +13,7 @@ MAT_LAMBERT_SOLID, MAT_LAMBERT_CHECKER, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE,
     MAT_ROUGH_GGX, MAT_ROUGH_BECKMANN, MAT_NULL = range(9)
 PRIM_SPHERE, PRIM_PLANE, PRIM_QUAD, PRIM_CUBE, PRIM_MESH = range(5)
 RNG_CTR, RNG_REF = 0, 1
+FLAG_FIXED_AABB = 1
 
 f32, u32, u64 = C.c_float, C.c_uint32, C.c_uint64
 
@@ -63,12 +64,12 @@ class Scene(C.Structure):
 class Options(C.Structure):
     _fields_ = [("abi_version", u32), ("rng_mode", u32), ("seed", u64),
                 ("row_begin", u32), ("row_end", u32), ("strip_rows", u32), ("n_parts", u32), ("part", u32),
-                ("_pad", u32), ("workspace_bytes", u64)]
+                ("flags", u32), ("workspace_bytes", u64)]
 
     @classmethod
     def make(cls, rng_mode=RNG_CTR, seed=0, row_begin=0, row_end=0, strip_rows=1, n_parts=1, part=0,
-             workspace_bytes=0):
-        return cls(ABI_VERSION, rng_mode, seed, row_begin, row_end, strip_rows, n_parts, part, 0, workspace_bytes)
+             workspace_bytes=0, flags=0):
+        return cls(ABI_VERSION, rng_mode, seed, row_begin, row_end, strip_rows, n_parts, part, flags, workspace_bytes)
 
 
 class Stats(C.Structure):

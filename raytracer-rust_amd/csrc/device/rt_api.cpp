@@ -81,6 +81,7 @@ struct mi355rt_context {
     int cu_count = 0;
     int blocks_per_cu[KERNEL_VARIANTS] = {}, vgprs[KERNEL_VARIANTS] = {}, sgprs = 0;
     uint32_t variant = KERNEL_LOCKSTEP;  // chosen per scene in set_scene
+    bool has_mesh = false;
     uint32_t guided_mult = 16;           // run length = (left in shard) / (guided_mult * waves per shard); 16 measured best at 1/8-image launches
     uint32_t inline_steps = 0;           // 1 when several meshes share the list (many rays miss a mesh's root box: teapot +5..12 %), 0 for a single mesh (semesterbild -10 % otherwise)
     uint32_t trav_min = 24;              // measured optimum 24-32 on semesterbild / teapot (tools/ab_kernel.py)
@@ -257,6 +258,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         const uint32_t k = sc->materials[i].kind;
         simple_mats = simple_mats && (k == MI355RT_MAT_LAMBERT_SOLID || k == MI355RT_MAT_EMISSIVE || k == MI355RT_MAT_NULL);
     }
+    ctx->has_mesh = has_mesh;
     ctx->variant = has_mesh ? KERNEL_STATE_MACHINE : (simple_mats ? KERNEL_LOCKSTEP_SIMPLE : KERNEL_LOCKSTEP);
     if (const char* e = std::getenv("MI355RT_KERNEL")) {            // A/B override (tools/): 0 lockstep, 1 lockstep+mesh, 2 state machine, 3 lockstep simple
         const int v = std::atoi(e);
@@ -349,9 +351,13 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         ctx->rows_valid = false;
     }
     const uint32_t rng_mode = opt ? opt->rng_mode : (uint32_t)MI355RT_RNG_CTR;
+    const bool fixed_aabb = opt && (opt->flags & MI355RT_FLAG_FIXED_AABB) != 0u;
+    if (opt && (opt->flags & ~MI355RT_FLAG_FIXED_AABB) != 0u) return fail(MI355RT_ERR_INVALID, "options.flags has unknown bits");
+    if (fixed_aabb && rng_mode != MI355RT_RNG_CTR) return fail(MI355RT_ERR_INVALID, "MI355RT_FLAG_FIXED_AABB needs MI355RT_RNG_CTR (the replay mode reproduces the reference as it is)");
+    const uint32_t variant = (fixed_aabb && ctx->has_mesh) ? (uint32_t)KERNEL_STATE_MACHINE_FIXAABB : ctx->variant;   // without a mesh the flag changes nothing
     const uint64_t seed = opt ? opt->seed : 0;
     const uint32_t n_rows = (uint32_t)ctx->rows_host.size();
-    if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs[ctx->variant]; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
+    if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs[variant]; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
     if (n_rows == 0) return MI355RT_OK;
 
     if (!same_rows) {
@@ -414,7 +420,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
         r.spp = (uint32_t)spp; r.inv_spp = 1.0f / (float)s1;                             // renderer.rs:85
         r.accum = (float*)d_accum; r.accum_load = s0 != 0 ? 1u : 0u;
-        const uint32_t resident = (uint32_t)(ctx->cu_count * ctx->blocks_per_cu[ctx->variant]);
+        const uint32_t resident = (uint32_t)(ctx->cu_count * ctx->blocks_per_cu[variant]);
         block_threads = BLOCK_THREADS;
         std::vector<float> band_ms;
         for (uint32_t b = 0; b < n_bands; ++b) {
@@ -440,7 +446,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             if (ctx->timing && !stats) { pe0 = ctx->pool_get(); pe1 = ctx->pool_get(); pe2 = ctx->pool_get(); if (!pe0 || !pe1 || !pe2) return fail(MI355RT_ERR_HIP, "event pool"); }
             if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], stream));
             if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
-            if (launch_render_ctr(p, ctx->variant, grid, stream) != 0) return fail(MI355RT_ERR_HIP, "k_render_ctr launch failed");
+            if (launch_render_ctr(p, variant, grid, stream) != 0) return fail(MI355RT_ERR_HIP, "k_render_ctr launch failed");
             if (stats) HIP_TRY(hipEventRecord(ctx->ev[1], stream));
             if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
             if (launch_resolve(r, stream) != 0) return fail(MI355RT_ERR_HIP, "k_resolve launch failed");

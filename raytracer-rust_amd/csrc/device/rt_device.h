@@ -89,7 +89,8 @@ enum : uint32_t {
     KERNEL_LOCKSTEP_MESH = 1,    // same loop with the per-lane BVH walk inlined (A/B reference for the state machine)
     KERNEL_STATE_MACHINE = 2,    // wave-voted TRAV / TOP / SHADE blocks (scenes with meshes)
     KERNEL_LOCKSTEP_SIMPLE = 3,  // KERNEL_LOCKSTEP for scenes whose materials are only Lambertian (solid) / Emissive / Null
-    KERNEL_VARIANTS = 4
+    KERNEL_STATE_MACHINE_FIXAABB = 4,   // KERNEL_STATE_MACHINE with the opt-in slab test (MI355RT_FLAG_FIXED_AABB)
+    KERNEL_VARIANTS = 5
 };
 
 struct ResolveParams {

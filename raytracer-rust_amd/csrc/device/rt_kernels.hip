@@ -359,6 +359,8 @@ DI void mesh_setup(cprim_t pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {
     m.best_t = t_max; m.best_tri = 0xFFFFFFFFu; m.leaf_b = 0; m.leaf_a = 0;
 }
 // Visit m.node (box test, aabb.rs:27-45).  Afterwards either m.node moved on, or a leaf is pending (m.leaf_b > 0).
+// FIXED_AABB: MI355RT_FLAG_FIXED_AABB -- a box is missed only when t_max < t_min (the reference misses on <=, aabb.rs:41).
+template <bool FIXED_AABB = false>
 DI void mesh_step(const float4* __restrict__ n4, float t_min, MeshTrav& m) {
     // 32-bit byte offset from the uniform base: the load takes the base from SGPRs instead of a 64-bit per-lane address
     // (node and triangle counts are validated against 2^26 at upload)
@@ -368,11 +370,11 @@ DI void mesh_step(const float4* __restrict__ n4, float t_min, MeshTrav& m) {
     float tmin = t_min, tmax = m.best_t;
     bool ok = true;
     {   float t0 = (q0.x - m.ro.x) * m.ix, t1 = (q1.x - m.ro.x) * m.ix; if (m.ix < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
+        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(FIXED_AABB ? (tmax < tmin) : (tmax <= tmin)); }
     {   float t0 = (q0.y - m.ro.y) * m.iy, t1 = (q1.y - m.ro.y) * m.iy; if (m.iy < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
+        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(FIXED_AABB ? (tmax < tmin) : (tmax <= tmin)); }
     {   float t0 = (q0.z - m.ro.z) * m.iz, t1 = (q1.z - m.ro.z) * m.iz; if (m.iz < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(tmax <= tmin); }
+        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(FIXED_AABB ? (tmax < tmin) : (tmax <= tmin)); }
     // Branch-free successor: missed inner node -> its escape index `a`; hit leaf -> stay, triangles pending; every other
     // case (hit inner node: left child first; missed leaf: its successor) -> node + 1.
     const bool inner = b == 0u, take_leaf = ok && !inner;
@@ -939,7 +941,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per
 // ===================================================================================================
 enum : uint32_t { ST_IDLE = 0, ST_TOP = 1, ST_TRAV = 2, ST_SHADE = 3 };
 
-__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm(const RenderParams P) {
+template <bool FIXED_AABB>
+DI void render_ctr_state_machine(const RenderParams& P) {
     cprim_t prims = (cprim_t)(P.prims);
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
@@ -986,10 +989,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
                 if (wm == 0ull || __popcll(wm) * MI355RT_TRAV_BIAS < __popcll(lm)) break;
                 MI355RT_COUNT(0, wm);
                 if (walking) {
-                    mesh_step(n4, EPS, mt);
+                    mesh_step<FIXED_AABB>(n4, EPS, mt);
 #pragma unroll
                     for (int u = 1; u < MI355RT_TRAV_UNROLL; ++u)
-                        if (mt.leaf_b == 0u && mt.node < mt.end) mesh_step(n4, EPS, mt);
+                        if (mt.leaf_b == 0u && mt.node < mt.end) mesh_step<FIXED_AABB>(n4, EPS, mt);
                 }
             }
             MI355RT_COUNT(1, __ballot(state == ST_TRAV && mt.leaf_b != 0u));
@@ -1020,7 +1023,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
 #pragma unroll 1
                                 for (uint32_t k = 0; k < P.inline_steps; ++k) {
                                     if (mt.leaf_b != 0u || mt.node >= mt.end) break;
-                                    mesh_step(n4, EPS, mt);
+                                    mesh_step<FIXED_AABB>(n4, EPS, mt);
                                 }
                                 if (mt.leaf_b == 0u && mt.node >= mt.end) walk_done = true;   // walked off the tree without meeting a leaf
                             }
@@ -1057,6 +1060,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
     if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }
 }
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm(const RenderParams P) { render_ctr_state_machine<false>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm_fixaabb(const RenderParams P) { render_ctr_state_machine<true>(P); }
 
 // ===================================================================================================
 // k_resolve -- ordered per-pixel sum, 1/spp, sqrt gamma, pack (renderer.rs:100-120), without LDS.
@@ -1155,6 +1160,7 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
         case KERNEL_LOCKSTEP:        hipLaunchKernelGGL(k_render_ctr_nomesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_MESH:   hipLaunchKernelGGL(k_render_ctr_mesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_SIMPLE: hipLaunchKernelGGL(k_render_ctr_simple, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_STATE_MACHINE_FIXAABB: hipLaunchKernelGGL(k_render_ctr_sm_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         default:                     hipLaunchKernelGGL(k_render_ctr_sm, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
     }
     return (int)hipGetLastError();
@@ -1172,6 +1178,7 @@ int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs,
     const void* fn = variant == KERNEL_LOCKSTEP ? reinterpret_cast<const void*>(k_render_ctr_nomesh)
                    : variant == KERNEL_LOCKSTEP_MESH ? reinterpret_cast<const void*>(k_render_ctr_mesh)
                    : variant == KERNEL_LOCKSTEP_SIMPLE ? reinterpret_cast<const void*>(k_render_ctr_simple)
+                   : variant == KERNEL_STATE_MACHINE_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_sm_fixaabb)
                                                        : reinterpret_cast<const void*>(k_render_ctr_sm);
     int nb = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK_THREADS, 0);

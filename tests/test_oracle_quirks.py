@@ -156,3 +156,51 @@ def test_hip_path_reproduces_the_quirks(native, oracle_mod, abi):
     # the green mesh shows in front of the (nearer!) red quad only when it is listed first; listed second it is culled
     assert means["mesh then quad"][1] > means["quad then mesh"][1] + 0.01
     assert means["quad then mesh"][0] > means["mesh then quad"][0] + 0.01
+
+
+def _flat_leaf_case(abi, host):
+    sc = _scene(abi, [_prim(abi, abi.PRIM_MESH, IDENT + IDENT)], [_tri((-1, -1, 0), (1, -1, 0), (0, 1, 0))])
+    sc.c.materials[0].kind = abi.MAT_EMISSIVE; sc.c.materials[0].albedo[:] = (0.9, 0.1, 0.1)     # the triangle glows red
+    sc._bvh = host.attach_bvh(sc)
+    cam = abi.Camera(); cam.position[:] = [0, 0, 8]; cam.forward[:] = [0, 0, -1]; cam.right[:] = [1, 0, 0]; cam.true_up[:] = [0, 1, 0]
+    cam.half_width, cam.half_height = 0.4, 0.3
+    return sc, cam, abi.Settings(32, 24, 2, 4)
+
+
+def test_fixed_aabb_flag_makes_flat_leaves_visible_in_the_oracle(native, oracle_mod, abi):
+    """MI355RT_FLAG_FIXED_AABB (opt-in, not the reference): the slab test misses only on t_max < t_min, so the flat
+    triangle of test_zero_thickness_boxes_never_hit is seen.  Without the flag the image is the miss colour everywhere."""
+    host, _ = native
+    sc, cam, st = _flat_leaf_case(abi, host)
+    ref_p, ref_l, _ = oracle_mod.render(sc, cam, st, abi.Options.make())
+    fix_p, fix_l, _ = oracle_mod.render(sc, cam, st, abi.Options.make(flags=abi.FLAG_FIXED_AABB))
+    assert (ref_p == 0xB4B4B4).all()                                   # sqrt(0.5) * 255 = 180 = 0xB4: only the miss colour
+    red = (fix_l[..., 0] > 0.8) & (fix_l[..., 1] < 0.2)
+    assert 0.02 < red.mean() < 0.5 and (fix_p[~red & (fix_l[..., 1] > 0.45)] == 0xB4B4B4).all()
+    again, _, _ = oracle_mod.render(sc, cam, st, abi.Options.make())    # the flag does not leak into the next call
+    assert np.array_equal(again, ref_p)
+
+
+@pytest.mark.gpu
+def test_hip_fixed_aabb_matches_the_oracle(native, oracle_mod, abi):
+    from conftest import load_for_both
+    host, device = native
+    sc, cam, st = _flat_leaf_case(abi, host)
+    flag = abi.Options.make(flags=abi.FLAG_FIXED_AABB)
+    gp, gl, gs = device.render(sc, cam, st, flag)
+    op, ol, cnt = oracle_mod.render(sc, cam, st, flag)
+    assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op) and gs.rays == cnt.rays
+    assert not np.array_equal(gp, device.render(sc, cam, st, abi.Options.make())[0])
+    for name in ("teapot", "semesterbild"):                              # real meshes: more triangles become visible, parity holds
+        s2 = load_for_both(name, oracle_mod, host, width=72, height=54, spp=4, max_depth=10)
+        gp, gl, gs = device.render(s2, s2.camera, s2.settings, flag)
+        op, ol, cnt = oracle_mod.render(s2, s2.camera, s2.settings, flag)
+        if name == "teapot":
+            assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and gs.rays == cnt.rays
+        else:
+            assert (np.sqrt(((gl.astype(np.float64) - ol) ** 2).sum(-1)) <= 1e-3).mean() >= 0.995
+        assert not np.array_equal(gp, device.render(s2, s2.camera, s2.settings, abi.Options.make())[0]) or name == "teapot"
+    with pytest.raises(RuntimeError, match="MI355RT_RNG_CTR"):
+        device.render(sc, cam, st, abi.Options.make(rng_mode=abi.RNG_REF, flags=abi.FLAG_FIXED_AABB))
+    with pytest.raises(RuntimeError, match="unknown bits"):
+        device.render(sc, cam, st, abi.Options.make(flags=0x10))
