@@ -4,6 +4,7 @@
 //
 //   rt_render <scene.json> [-o out.png] [--width W] [--height H] [--spp N] [--max-depth D]
 //             [--rng ctr|ref] [--seed S] [--skip-unknown] [--chunk N] [--pfm out.pfm] [--gpus N]
+// --fix-aabb / --fix-wo3 switch on the two opt-in fixes (MI355RT_FLAG_FIXED_AABB, wo3_four_index_stride): not the reference's image.
 // --gpus N deals row strips over HIP devices 0..N-1 from this one process (mi355rt_render_multi).
 // --chunk N renders N samples per pixel at a time and rewrites the PNG after every chunk (a preview that refines).
 #include <chrono>
@@ -16,7 +17,7 @@
 #include "../../../include/mi355rt.h"
 
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s <scene.json> [-o out.png] [--width W] [--height H] [--spp N] [--max-depth D] [--rng ctr|ref] [--seed S] [--skip-unknown] [--chunk N] [--pfm out.pfm] [--gpus N]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <scene.json> [-o out.png] [--width W] [--height H] [--spp N] [--max-depth D] [--rng ctr|ref] [--seed S] [--skip-unknown] [--chunk N] [--pfm out.pfm] [--gpus N] [--fix-aabb] [--fix-wo3]\n", argv[0]); return 2; }
     std::string scene_path = argv[1], out_path = "render_pt.png", pfm_path;
     mi355rt_load_overrides ov{}; mi355rt_options opt{}; uint32_t chunk = 0, gpus = 1;
     opt.abi_version = MI355RT_ABI_VERSION; opt.rng_mode = MI355RT_RNG_CTR; opt.strip_rows = 1; opt.n_parts = 1;
@@ -33,6 +34,8 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--chunk")) chunk = (uint32_t)std::atoi(next());
         else if (!std::strcmp(argv[i], "--pfm")) pfm_path = next();
         else if (!std::strcmp(argv[i], "--gpus")) gpus = (uint32_t)std::atoi(next());
+        else if (!std::strcmp(argv[i], "--fix-aabb")) opt.flags |= MI355RT_FLAG_FIXED_AABB;
+        else if (!std::strcmp(argv[i], "--fix-wo3")) ov.wo3_four_index_stride = 1;
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     std::printf("Attempting to load scene from: %s\n", scene_path.c_str());
