@@ -437,15 +437,17 @@ DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
     bool any = false;
     for (uint32_t i = 0; i < n_prims; ++i) {
         cprim_t pr = prims + i;
-        Hit h; bool hit = false;
+        bool hit = false;
+        // every routine writes its record only after its last rejection, so `best` itself is the output: no temporary
+        // record and no copy per accepted hit (the copies showed up as 8 v_mov per nesting level in the ISA)
         switch (pr->kind) {                               // wave-uniform: scalar branch
-            case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ro, rd, EPS, closest, h); break;
-            case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ro, rd, EPS, closest, h); break;
-            case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ro, rd, EPS, closest, h); break;
-            case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, i, ro, rd, EPS, closest, h); break;
-            default:                  if (HAS_MESH) hit = hit_mesh(pr, nodes, tris, ro, rd, EPS, closest, h); break;
+            case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ro, rd, EPS, closest, best); break;
+            case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ro, rd, EPS, closest, best); break;
+            case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ro, rd, EPS, closest, best); break;
+            case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, i, ro, rd, EPS, closest, best); break;
+            default:                  if (HAS_MESH) hit = hit_mesh(pr, nodes, tris, ro, rd, EPS, closest, best); break;
         }
-        if (hit) { closest = h.t; best = h; any = true; }
+        if (hit) { closest = best.t; any = true; }
     }
     if (any && hit_pending(best)) finish_cube_hit((const DevPrim*)prims, best, rd);
     return any;
@@ -1009,12 +1011,12 @@ DI void render_ctr_state_machine(const RenderParams& P) {
                 if (__ballot(mine) == 0ull) continue;
                 cprim_t pr = prims + i;
                 if (mine) {
-                    Hit h; bool hit = false; bool advance = true;
-                    switch (pr->kind) {                                       // wave-uniform: scalar branch
-                        case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ps.ro, ps.rd, EPS, closest, h); break;
-                        case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ps.ro, ps.rd, EPS, closest, h); break;
-                        case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ps.ro, ps.rd, EPS, closest, h); break;
-                        case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, i, ps.ro, ps.rd, EPS, closest, h); break;
+                    bool hit = false; bool advance = true;
+                    switch (pr->kind) {                                       // wave-uniform: scalar branch; `best` is written in place (see hit_scene)
+                        case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ps.ro, ps.rd, EPS, closest, best); break;
+                        case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ps.ro, ps.rd, EPS, closest, best); break;
+                        case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ps.ro, ps.rd, EPS, closest, best); break;
+                        case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, i, ps.ro, ps.rd, EPS, closest, best); break;
                         default:
                             if (!walk_done) {
                                 // Most rays leave a mesh within a few box tests (they miss its root or upper boxes):
@@ -1027,11 +1029,11 @@ DI void render_ctr_state_machine(const RenderParams& P) {
                                 }
                                 if (mt.leaf_b == 0u && mt.node >= mt.end) walk_done = true;   // walked off the tree without meeting a leaf
                             }
-                            if (walk_done) { hit = mesh_finalize(pr, t4, mt, ps.ro, ps.rd, EPS, closest, h); walk_done = false; }
+                            if (walk_done) { hit = mesh_finalize(pr, t4, mt, ps.ro, ps.rd, EPS, closest, best); walk_done = false; }
                             else { state = ST_TRAV; advance = false; }
                             break;
                     }
-                    if (hit) { closest = h.t; best = h; any_hit = true; }
+                    if (hit) { closest = best.t; any_hit = true; }
                     if (advance) ++cursor;
                 }
             }
