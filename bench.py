@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X render loop (contract in the task statement / DESIGN.md).
+"""bench.py -- headline benchmark of the MI355X render loop (contract in the task statement / DESIGN.md section 6).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE full render of the BASELINE.json config[1] workload -- cornell-box scene.json at
-800x600, 256 spp, max_bounces 30 -- through the C ABI with the scene already resident in HBM:
-path-tracing kernel + ordered resolve kernel on every rank's row strips, then (N > 1) one RCCL gather of
-the packed rows to rank 0 and the de-interleave.  The image is fixed, so scaling is STRONG.
+A "step" is ONE full render of the workload -- by default BASELINE.json configs[1]: cornell-box scene.json at
+800x600, 256 spp, max_bounces 30 -- through the C ABI with the scene already resident in HBM: path-tracing
+kernel + ordered resolve kernel on every rank's row strips, then (N > 1) one RCCL all-gather of the packed rows
+and the de-interleave.  The image is fixed, so scaling is STRONG.
 value = width*height*spp*K / max-over-ranks wall time of the K steps, in Msamples/s.
 
 Extra objects in the JSON line:
-  roofline     dominant kernel (k_render_ctr): algorithmic bytes per launch (SURVEY.md 8d formula with the
-               measured rays/sample) / mean launch duration from HIP events recorded on the launch
-               stream over the timed region.  The scene records live in SGPRs/L2, so `frac` can exceed 1
-               against HBM; the truly binding unit is the f32 VALU (DESIGN.md "Roofline").
-  cpu_baseline the C++ oracle ("port" of the reference's rayon loop, reference RNG stream) timed on the
-               host cores on a bounded row sample of the same workload (rank 0, N = 1 only).
+  roofline     the dominant kernel (k_render_ctr_*) against the unit that binds it, the f32 VALU issue rate:
+               achieved = SQ_INSTS_VALU per step (PMC, profiles/pmc_counters.json, taken on THIS kernel -- the file
+               carries a hash of the kernel sources and the line says "pmc": "stale" instead of numbers when it
+               differs) / the kernel's time per step, measured live with HIP events on the launch stream over the
+               timed region; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.
+               `hbm` = the HBM bytes the counters saw (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) against 8 TB/s.
+               `logical_bytes_model` = SURVEY.md 8d's algorithmic bytes; they are served from SGPRs / L2, never reach
+               HBM, and therefore carry no fraction.
+  cpu_baseline the C++ oracle ("port" of the reference's rayon loop, reference RNG stream) timed on the host cores
+               on a bounded row sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import importlib
@@ -30,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # BASELINE.json configs[1..3]; configs[0] is the CPU plumbing case, configs[4] the 8-GPU case
+    # BASELINE.json configs[1..4]; configs[0] is the CPU plumbing case
     "cornell-box-800x600x256-d30": ("data/scenes/tungsten/cornell-box/scene.json", 800, 600, 256, 30, False),
     "teapot-800x600x256-d64": ("data/scenes/tungsten/teapot/scene.json", 800, 600, 256, 64, True),
     "veach-mis-1280x720x1024-d16": ("data/scenes/tungsten/veach-mis/scene.json", 1280, 720, 1024, 16, False),
@@ -40,6 +44,32 @@ WORKLOADS = {
 REC_BYTES = {0: 16, 1: 24, 2: 64, 3: 128, 4: 128}     # sphere, plane, quad, cube, mesh header
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_SIMDS, VALU_CLOCK_HZ, VALU_CYCLES_PER_WAVE64_INST = 1024, 2.4e9, 2     # 256 CUs x 4 SIMDs; 157.3 TFLOP/s f32 = 1024 x 32 lanes x 2 x 2.4 GHz
+KERNEL_NAMES = {0: "k_render_ctr_nomesh", 1: "k_render_ctr_mesh", 2: "k_render_ctr_sm", 3: "k_render_ctr_simple", 4: "k_render_ctr_sm_fixaabb"}
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def load_pmc(workload, kernel_hash):
+    """Counters of the dominant kernel per STEP (all bands of one full render) for `workload`, or the reason there are none."""
+    if not os.path.exists(PMC_FILE):
+        return None, "absent"
+    try:
+        doc = json.load(open(PMC_FILE))
+    except Exception:
+        return None, "unreadable"
+    if doc.get("kernel_hash") != kernel_hash:
+        return None, "stale"
+    rec = doc.get("workloads", {}).get(workload)
+    return (rec, "fresh") if rec else (None, "absent")
 
 
 def main():
@@ -48,7 +78,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cornell-box-800x600x256-d30", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample; 0 disables it")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample; 0 disables it")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="frames in flight (own stream + workspace each): 2 lets frame k's resolve + gather overlap frame k+1's tracing. "
+                         "0 = auto: 1 on one GPU (clean per-kernel timing), 2 on several")
+    ap.add_argument("--tail-parts", type=int, default=0,
+                    help="after the timed region also time 1/P-image launches (strip part p of P, every p) on this GPU: "
+                         "what one of P GPUs would run; reports ideal (full/P) vs measured")
     ap.add_argument("--save-png", default="")
     args = ap.parse_args()
 
@@ -66,6 +102,7 @@ def main():
     host = importlib.import_module("raytracer-rust_amd.host")
     device = importlib.import_module("raytracer-rust_amd.device")
     rtdist = importlib.import_module("raytracer-rust_amd.distributed")
+    build = importlib.import_module("raytracer-rust_amd.build")
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
@@ -86,13 +123,19 @@ def main():
 
     path, W, H, spp, depth, skip_unknown = WORKLOADS[args.workload]
     scene = host.LoadedScene(os.path.join(ROOT, path), W, H, spp, depth, skip_unknown_primitives=skip_unknown)   # product loader (C++)
-    ctx = device.Context(local_rank)
-    ctx.set_scene(scene, scene.camera, scene.settings)                 # scene resident in HBM from here on
     plan = rtdist.make_plan(H, W, world)
     opt = plan.options_for(abi, rank)
     n_local_rows = len(plan.rows[rank])
-    local = torch.zeros((plan.max_rows, W), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    depth_pipe = args.pipeline if args.pipeline > 0 else (2 if world > 1 else 1)
+    # One frame slot = its own context (radiance workspace, work counters), output buffer and stream, so that two frames
+    # never share scratch memory.  The scene is resident in HBM in every slot from here on.
+    slots = []
+    for i in range(depth_pipe):
+        ctx = device.Context(local_rank)
+        ctx.set_scene(scene, scene.camera, scene.settings)
+        slots.append({"ctx": ctx, "local": torch.zeros((plan.max_rows, W), dtype=torch.int32, device=dev),
+                      "stream": torch.cuda.current_stream() if depth_pipe == 1 else torch.cuda.Stream(device=dev)})
+    ctx0 = slots[0]["ctx"]
 
     def sync_all():
         if world > 1:
@@ -100,32 +143,48 @@ def main():
         torch.cuda.synchronize()
 
     image = None
+    frame = 0
 
     def step():
-        nonlocal image
-        ctx.render(local.data_ptr(), None, opt, stream)               # enqueue only: no host sync inside
-        image = rtdist.gather_image(local.cpu() if rehearse else local, plan, rank)
+        nonlocal image, frame
+        s = slots[frame % depth_pipe]
+        frame += 1
+        with torch.cuda.stream(s["stream"]):
+            s["ctx"].render(s["local"].data_ptr(), None, opt, s["stream"].cuda_stream)     # enqueue only: no host sync inside
+            image = rtdist.gather_image(s["local"].cpu() if rehearse else s["local"], plan, rank)
 
     for _ in range(args.warmup):
         step()
     sync_all()
-    ctx.set_timing(True)
+    for s in slots:
+        s["ctx"].set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    k_render_ms, k_resolve_ms, launches = ctx.read_timing()
-    ctx.set_timing(False)
+    k_render_ms = k_resolve_ms = 0.0
+    launches = 0
+    for s in slots:
+        a, b, n = s["ctx"].read_timing()
+        k_render_ms += a; k_resolve_ms += b; launches += n
+        s["ctx"].set_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    final_image = image
 
     # one extra (untimed) step with counters for rays/sample
-    st = ctx.render(local.data_ptr(), None, opt, stream, want_stats=True)
+    torch.cuda.synchronize()
+    st = ctx0.render(slots[0]["local"].data_ptr(), None, opt, slots[0]["stream"].cuda_stream, want_stats=True)
     local_samples = n_local_rows * W * spp
     rays_per_sample = st.rays / max(st.samples, 1)
+    variant = ctx0.kernel_variant()
+
+    tail = None
+    if args.tail_parts > 1 and world == 1:
+        tail = measure_tail(abi, rtdist, ctx0, slots[0], H, W, args.tail_parts, max(3, args.steps // 2), k_render_ms / max(args.steps, 1), torch)
 
     total_samples = W * H * spp
     value = total_samples * args.steps / elapsed / 1e6
@@ -142,80 +201,132 @@ def main():
                 _, nodes_per_ray, tris_per_ray = run_cpu_baseline(abi, scene, W, H, spp, 0.5)
         except Exception as e:                 # e.g. no g++ on the box
             cpu_baseline = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+        # Kernel time per STEP (= per full render of this rank's rows, all workspace bands together), from the HIP events the
+        # library recorded around every launch of the timed region.
+        render_ms_per_step = k_render_ms / max(args.steps, 1)
+        resolve_ms_per_step = k_resolve_ms / max(args.steps, 1)
+        share = local_samples / total_samples            # a rank renders its strips only; counters were taken on the whole image
+        khash = build.kernel_hash()
+        pmc, pmc_state = load_pmc(args.workload, khash)
+        peak_inst = VALU_SIMDS * VALU_CLOCK_HZ / VALU_CYCLES_PER_WAVE64_INST
+        achieved = frac = lane_util = traffic = None
+        hbm = None
+        if pmc and render_ms_per_step > 0:
+            insts = pmc["valu_wave_insts_per_step"] * share
+            achieved = insts / (render_ms_per_step * 1e-3)
+            frac = achieved / peak_inst
+            lane_util = pmc.get("valu_lane_utilisation")
+            traffic = int(pmc["hbm_bytes_per_step"] * share)
+            gbs = traffic / (render_ms_per_step * 1e-3) / 1e9
+            hbm = {"traffic_bytes": traffic, "achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
+                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB x 1024 per step; x2 = gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md, HBM)"}
         bytes_per_sample = rays_per_sample * (rec + 48 + nodes_per_ray * 32 + tris_per_ray * 48) + 16.0 / spp
-        ms_per_launch = k_render_ms / max(launches, 1)
-        achieved = bytes_per_sample * local_samples / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-        traffic = None
-        valu = None                              # the unit that really binds: f32 VALU issue slots (PMC instruction count / live kernel time)
-        pmc = os.path.join(ROOT, "profiles", "pmc_hbm_bytes.json")
-        if os.path.exists(pmc):
-            try:
-                rec_pmc = json.load(open(pmc)).get(args.workload, {})
-                traffic = rec_pmc.get("k_render_ctr_hbm_bytes_per_launch")
-                if traffic is not None:          # measured on the whole image in one launch; a rank renders local_samples of it
-                    traffic = int(traffic * local_samples / total_samples)
-                insts = rec_pmc.get("k_render_ctr_valu_insts_per_launch")
-                if insts is not None and ms_per_launch > 0:
-                    peak = VALU_SIMDS * VALU_CLOCK_HZ / VALU_CYCLES_PER_WAVE64_INST
-                    rate = insts * local_samples / total_samples / (ms_per_launch * 1e-3)
-                    valu = {"wave_insts_per_launch": int(insts * local_samples / total_samples), "achieved_ginst_s": round(rate / 1e9, 1),
-                            "peak_ginst_s": round(peak / 1e9, 1), "frac": round(rate / peak, 4),
-                            "lane_utilisation": rec_pmc.get("k_render_ctr_valu_lane_utilisation"),
-                            "note": "SQ_INSTS_VALU (PMC, profiles/) / live kernel time vs 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
-            except Exception:
-                traffic = None
         result = {
-            "metric": "Msamples/s (pixels x spp / s) at 800x600x256spp; 1/2/4/8-GPU scaling",
+            "metric": f"Msamples/s (pixels x spp / s) at {W}x{H}x{spp}spp; 1/2/4/8-GPU scaling",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (reference's own cornell-box scene.json; no external data)",
+            "vs_baseline": None, "dtype": "f32", "data": f"synthetic (the reference's own {os.path.basename(os.path.dirname(path)) or path} scene file; no external data)",
             "config": {"workload": args.workload, "scene": path, "width": W, "height": H, "spp": spp, "max_bounces": depth,
                        "rng": "ctr (Philox4x32-10 per ray)", "parallelism": f"row strips of {plan.strip_rows} dealt round-robin over {world} GPU(s)"
-                       + (", RCCL gather to rank 0" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_render_ctr", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_sample": round(bytes_per_sample, 1), "rays_per_sample": round(rays_per_sample, 4),
-                         "kernel_ms_per_launch": round(ms_per_launch, 4), "resolve_ms_per_launch": round(k_resolve_ms / max(launches, 1), 4),
-                         "launches_timed": launches, "samples_per_launch": local_samples,
-                         "valu": valu,
-                         "note": "scene records are SGPR/L2 resident, so algorithmic bytes never reach HBM; the binding unit is the f32 VALU (see valu)"},
+                       + (f", RCCL {rtdist.collective_name(rehearse)} of the packed rows" if world > 1 else ""),
+                       "frames_in_flight": depth_pipe},
+            "roofline": {"bound": "valu", "kernel": KERNEL_NAMES.get(variant, "k_render_ctr"),
+                         "achieved": None if achieved is None else round(achieved / 1e9, 1), "peak": round(peak_inst / 1e9, 1),
+                         "unit": "G wave-instructions/s", "frac": None if frac is None else round(frac, 4), "traffic": traffic,
+                         "lane_utilisation": lane_util,
+                         "useful_frac": None if frac is None or lane_util is None else round(frac * lane_util, 4),
+                         "hbm": hbm,
+                         "kernel_ms_per_step": round(render_ms_per_step, 4), "resolve_ms_per_step": round(resolve_ms_per_step, 4),
+                         "kernel_launches_per_step": launches / max(args.steps, 1), "samples_per_step": local_samples,
+                         "pmc": pmc_state, "kernel_hash": khash,
+                         "logical_bytes_model": {"bytes_per_sample": round(bytes_per_sample, 1), "rays_per_sample": round(rays_per_sample, 4),
+                                                 "bytes_per_step": int(bytes_per_sample * local_samples),
+                                                 "note": "SURVEY.md 8d algorithmic bytes; SGPR/L2 resident, never reach HBM -- a model, not an HBM fraction"},
+                         "note": "achieved = SQ_INSTS_VALU per step (PMC, profiles/pmc_counters.json, same kernel hash) / live HIP-event kernel time per step; "
+                                 "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction"
+                                 + ("; frames overlap on two streams here, so the kernel's event time includes time it shared the chip" if depth_pipe > 1 else "")},
             "cpu_baseline": cpu_baseline,
+            **({"tail": tail} if tail else {}),
             **({"rehearsal": "all ranks on cuda:0 over gloo -- plumbing check only, NOT a measurement"} if rehearse else {}),
             "kernel": {"vgprs": st.kernel_vgprs, "grid_blocks": st.grid_blocks, "block_threads": st.block_threads, "bands": st.bands},
         }
-        if image is not None:
-            result["image_checksum"] = int(image.to(torch.int64).sum().item())      # identical for every N (RNG keyed by absolute row)
-        if args.save_png and image is not None:
+        if final_image is not None:
+            result["image_checksum"] = int(final_image.to(torch.int64).sum().item())      # identical for every N and pipeline depth (RNG keyed by absolute row)
+        if args.save_png and final_image is not None:
             import numpy as np
-            host.write_png(args.save_png, image.cpu().numpy().astype(np.uint32), W, H)
+            host.write_png(args.save_png, final_image.cpu().numpy().astype(np.uint32), W, H)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for s in slots:
+        s["ctx"].close()
     return result
 
 
+def measure_tail(abi, rtdist, ctx, slot, H, W, parts, steps, full_render_ms, torch):
+    """What ONE of `parts` GPUs would run: strip part p of `parts` of the same image, timed on this GPU for every p.
+    ideal = full-image kernel time / parts; the difference is the launch tail (waves draining their last paths)."""
+    plan = rtdist.make_plan(H, W, parts)
+    stream = slot["stream"].cuda_stream
+    per_part = []
+    for p in range(parts):
+        o = plan.options_for(abi, p)
+        ctx.render(slot["local"].data_ptr(), None, o, stream)                  # warm: uploads this part's row table
+        torch.cuda.synchronize()
+        ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.render(slot["local"].data_ptr(), None, o, stream)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        a, b, _ = ctx.read_timing()
+        ctx.set_timing(False)
+        per_part.append((a / steps, b / steps, wall))
+    worst = max(per_part, key=lambda x: x[2])
+    ideal = full_render_ms / parts
+    return {"parts": parts, "strip_rows": plan.strip_rows, "ideal_render_ms": round(ideal, 4),
+            "render_ms_max": round(max(x[0] for x in per_part), 4), "render_ms_mean": round(sum(x[0] for x in per_part) / parts, 4),
+            "resolve_ms_max": round(max(x[1] for x in per_part), 4), "step_wall_ms_max": round(worst[2], 4),
+            "tail_efficiency": round(ideal / max(x[0] for x in per_part), 4),
+            "note": "one GPU renders strip part p of P of the image, every p in turn (no gather): an upper bound for P-GPU strong scaling"}
+
+
 def run_cpu_baseline(abi, scene, W, H, spp, target_seconds):
-    """Times the CPU oracle (reference RNG stream, tail-first folding, all host cores given to this
-    job) on every k-th row of the same workload; rows are independent and their cost is additive."""
+    """Times the CPU oracle (reference RNG stream, tail-first folding) with one thread per host core this job may use on
+    rows spread evenly over the image; rows are the reference's unit of parallelism (rayon par_chunks_mut, renderer.rs:87)
+    and are handed to the threads from a shared queue.  At least 4 rows per thread; when whole rows at full spp would
+    overshoot the budget (1920 x 4096 spp: 26 core-seconds per row) the sample keeps the rows and lowers spp -- the cost of a
+    sample does not depend on how many of them a pixel gets."""
+    import copy
     import oracle
     oracle.build()
-    cores = min(len(os.sched_getaffinity(0)), 16) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # Rows are the unit of parallelism (one row per thread at a time, like rayon's par_chunks_mut), so the sample
-    # is always a multiple of `cores` rows, spread evenly over the image.  Pilot: one row per core.
+    nproc = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc
+    threads = cores                                          # every core this process may run on
+
     def every(n_rows):
-        n_rows = max(cores, min(H, (n_rows // cores) * cores))
-        return abi.Options.make(rng_mode=abi.RNG_REF, strip_rows=1, n_parts=max(1, -(-H // n_rows)), part=0)   # ceil: never more than n_rows rows
-    _, _, c0 = oracle.render(scene, scene.camera, scene.settings, every(cores), threads=cores, want_linear=False)
-    rate = c0.samples / max(c0.seconds, 1e-9)
-    opt = every(int(target_seconds * rate / (W * spp)))
-    parts = opt.n_parts
-    _, _, c = oracle.render(scene, scene.camera, scene.settings, opt, threads=cores, want_linear=False)
+        n_rows = max(1, min(H, n_rows))
+        return abi.Options.make(rng_mode=abi.RNG_REF, strip_rows=1, n_parts=max(1, H // n_rows), part=0)
+    # pilot: one row per thread at a reduced spp
+    st = copy.copy(scene.settings)
+    pilot = abi.Settings(W, H, max(1, min(spp, 8)), st.max_depth)
+    _, _, c0 = oracle.render(scene, scene.camera, pilot, every(threads), threads=threads, want_linear=False)
+    rate = c0.samples / max(c0.seconds, 1e-9)                # samples/s with all threads busy
+    budget = target_seconds * rate                            # samples the budget buys
+    min_rows = 4 * threads
+    s_spp = spp
+    if budget < min_rows * W * spp:
+        s_spp = max(1, int(budget / (min_rows * W)))
+    n_rows = max(min_rows, int(budget / (W * s_spp)))
+    opt = every(n_rows)
+    sample_settings = abi.Settings(W, H, s_spp, st.max_depth)
+    _, _, c = oracle.render(scene, scene.camera, sample_settings, opt, threads=threads, want_linear=False)
     rows = len(abi.rows_selected(H, opt))
-    base = {"value": round(c.samples / c.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"every {parts}th row ({rows} of {H} rows, {c.samples} samples, {c.seconds:.1f} s) of the same scene/resolution/spp/depth; "
-                      "C++ restatement of the reference's rayon path with its ChaCha12 row streams",
+    base = {"value": round(c.samples / c.seconds / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "nproc": nproc, "cpu_model": cpu_model(), "threads": threads,
+            "sample": f"every {opt.n_parts}th row ({rows} of {H} rows = {rows / threads:.1f} per thread) at {s_spp} of {spp} spp, {c.samples} samples, {c.seconds:.1f} s; "
+                      "same scene/resolution/depth; C++ restatement of the reference's rayon path with its ChaCha12 row streams",
             "rays_per_sample": round(c.rays / max(c.samples, 1), 4)}
     return base, c.bvh_nodes / max(c.rays, 1), c.tri_tests / max(c.rays, 1)
 

@@ -44,6 +44,17 @@ def _host_deps():
     return _host_srcs() + hs + [os.path.join(ROOT, "include", "mi355rt.h")]
 
 
+def kernel_hash():
+    """sha256 over everything that decides the device code: kernel sources, the shared device header and the
+    hipcc flags.  profiles/pmc_counters.json records it, and bench.py refuses counters taken on another kernel."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in DEVICE_SRCS[:1] + [os.path.join(CSRC, "device", "rt_device.h")]:
+        h.update(open(f, "rb").read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -98,6 +98,11 @@ struct mi355rt_context {
     std::vector<uint32_t> rows_host;     // source of the async row-table upload; must outlive the copy
     bool rows_valid = false;             // ctx->rows already holds rows_host (same selection as the last call)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // The workspaces (rows, radiance, counters, stats) belong to one render at a time.  `done` is recorded behind the last
+    // operation of every render; a render enqueued on ANOTHER stream waits on it first, so two streams can never touch
+    // the workspaces concurrently (same stream: in-order execution already guarantees it).
+    hipEvent_t done = nullptr; hipStream_t last_stream = nullptr; bool have_last = false;
+    bool want_wave_times = false;        // MI355RT_WAVE_TIMES=1 at context creation (diagnostic builds)
     // timing pool (mi355rt_context_set_timing): event triples recorded around every kernel pair without
     // synchronising; mi355rt_context_read_timing sums them after the caller's own stream sync.
     bool timing = false;
@@ -306,6 +311,8 @@ int mi355rt_context_create(int hip_device, mi355rt_context** out_ctx) {
         }
     }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return fail(MI355RT_ERR_HIP, "hipEventCreate"); }
+    if (hipEventCreateWithFlags(&ctx->done, hipEventDisableTiming) != hipSuccess) { delete ctx; return fail(MI355RT_ERR_HIP, "hipEventCreate"); }
+    ctx->want_wave_times = std::getenv("MI355RT_WAVE_TIMES") != nullptr;
     *out_ctx = ctx;
     return MI355RT_OK;
 }
@@ -316,6 +323,7 @@ void mi355rt_context_destroy(mi355rt_context* ctx) {
     ctx->prims.release(); ctx->mats.release(); ctx->nodes.release(); ctx->tris.release(); ctx->rows.release();
     ctx->radiance.release(); ctx->counters.release(); ctx->stats.release(); ctx->fold_stack.release(); ctx->wave_times.release(); ctx->sky.release();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->done) (void)hipEventDestroy(ctx->done);
     for (auto& e : ctx->pool) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -344,9 +352,10 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
     hipStream_t stream = (hipStream_t)hip_stream;
     const mi355rt_settings& st = ctx->settings;
     RowSel sel; int rc = select_rows(st, opt, sel); if (rc) return rc;
+    if (ctx->have_last && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->done, 0));   // the previous render owned the workspaces
     const bool same_rows = ctx->rows_valid && sel.rows == ctx->rows_host;
     if (!same_rows) {
-        HIP_TRY(hipStreamSynchronize(stream));   // a previous call's row-table upload may still read rows_host
+        if (ctx->have_last) HIP_TRY(hipEventSynchronize(ctx->done));   // a previous call's row-table upload may still read rows_host
         ctx->rows_host.swap(sel.rows);
         ctx->rows_valid = false;
     }
@@ -399,9 +408,17 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         uint64_t ws_cap = (opt && opt->workspace_bytes) ? opt->workspace_bytes : (32ull << 30);   // 288 GB of HBM: default = the 2^31-sample band limit; only what a band needs is allocated
         uint64_t max_samples = std::min<uint64_t>(ws_cap / 16, (1ull << 31) - 2 * BATCH_MAX);
         if (max_samples < spp) return fail(MI355RT_ERR_INVALID, "workspace_bytes too small for one pixel (needs spp * 16 bytes)");
-        const uint64_t band_pixels_max = std::min<uint64_t>(max_samples / spp, total_pixels);
+        uint64_t band_pixels_max = std::min<uint64_t>(max_samples / spp, total_pixels);
+        // Only what a band needs is allocated.  When even that does not fit (another tenant on the GPU, a small device),
+        // halve the band and try again: more, smaller bands give the same image (tiling invariance), just more launches.
+        for (;;) {
+            rc = ctx->radiance.ensure((size_t)(band_pixels_max * spp * 4));
+            if (rc != MI355RT_ERR_OOM || band_pixels_max <= 1) break;
+            (void)hipGetLastError();
+            band_pixels_max = (band_pixels_max + 1) / 2;
+        }
+        if (rc) return rc;
         n_bands = (uint32_t)((total_pixels + band_pixels_max - 1) / band_pixels_max);
-        if ((rc = ctx->radiance.ensure((size_t)(band_pixels_max * spp * 4)))) return rc;
         const size_t ctr_words = (size_t)WORK_SHARDS * WORK_SHARD_STRIDE;            // per band
         if ((rc = ctx->counters.ensure((size_t)n_bands * ctr_words))) return rc;
         HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, (size_t)n_bands * ctr_words * sizeof(uint32_t), stream));
@@ -434,7 +451,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             const uint32_t grid = std::max(1u, std::min(resident, (min_runs + waves_per_block - 1) / waves_per_block));
             p.guided_div = std::max(1u, ctx->guided_mult * grid * waves_per_block / WORK_SHARDS);
             p.wave_times = nullptr;
-            if (std::getenv("MI355RT_WAVE_TIMES")) {
+            if (ctx->want_wave_times) {
                 ctx->wave_times_n = grid * waves_per_block;
                 if ((rc = ctx->wave_times.ensure((size_t)ctx->wave_times_n * WAVE_TIME_WORDS))) return rc;
                 HIP_TRY(hipMemsetAsync(ctx->wave_times.p, 0, (size_t)ctx->wave_times_n * WAVE_TIME_WORDS * 8, stream));
@@ -461,6 +478,8 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             }
         }
     }
+    HIP_TRY(hipEventRecord(ctx->done, stream));
+    ctx->last_stream = stream; ctx->have_last = true;
     if (stats) {
         unsigned long long h[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(h, ctx->stats.p, sizeof h, hipMemcpyDeviceToHost, stream));

@@ -15,6 +15,7 @@ struct JsonValue {
     enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
     bool b = false;
     double num = 0.0;
+    bool integral = false;      // Number: the token had no fraction and no exponent and no minus sign (what serde accepts for usize)
     std::string str;
     std::vector<JsonValue> arr;
     std::vector<std::pair<std::string, JsonValue>> obj;
@@ -47,6 +48,28 @@ public:
 private:
     const std::string& s_;
     size_t p_ = 0;
+    int depth_ = 0;
+    static constexpr int MAX_DEPTH = 128;      // serde_json's default recursion limit
+    struct Nest { JsonParser& p; explicit Nest(JsonParser& q) : p(q) { if (++p.depth_ > MAX_DEPTH) p.err("recursion limit exceeded"); } ~Nest() { --p.depth_; } };
+    // RFC 8259 number: -? (0 | [1-9][0-9]*) (\.[0-9]+)? ([eE][+-]?[0-9]+)?   -- strtod alone would also take hex, inf, nan, "1."
+    size_t number_end(bool& integral) const {
+        size_t q = p_; integral = true;
+        if (q < s_.size() && s_[q] == '-') { ++q; integral = false; }
+        if (q >= s_.size() || !(s_[q] >= '0' && s_[q] <= '9')) return p_;
+        if (s_[q] == '0') ++q; else while (q < s_.size() && s_[q] >= '0' && s_[q] <= '9') ++q;
+        if (q < s_.size() && s_[q] == '.') {
+            size_t d = ++q; while (q < s_.size() && s_[q] >= '0' && s_[q] <= '9') ++q;
+            if (q == d) return p_;
+            integral = false;
+        }
+        if (q < s_.size() && (s_[q] == 'e' || s_[q] == 'E')) {
+            ++q; if (q < s_.size() && (s_[q] == '+' || s_[q] == '-')) ++q;
+            size_t d = q; while (q < s_.size() && s_[q] >= '0' && s_[q] <= '9') ++q;
+            if (q == d) return p_;
+            integral = false;
+        }
+        return q;
+    }
     [[noreturn]] void err(const char* what) const { throw std::runtime_error(std::string("JSON: ") + what + " at byte " + std::to_string(p_)); }
     void ws() { while (p_ < s_.size() && (s_[p_] == ' ' || s_[p_] == '\t' || s_[p_] == '\n' || s_[p_] == '\r')) ++p_; }
     bool lit(const char* w) { size_t n = std::char_traits<char>::length(w); if (s_.compare(p_, n, w) == 0) { p_ += n; return true; } return false; }
@@ -56,6 +79,7 @@ private:
         char c = s_[p_];
         JsonValue v;
         if (c == '{') {
+            Nest nest(*this);
             v.kind = JsonValue::Object; ++p_; ws();
             if (p_ < s_.size() && s_[p_] == '}') { ++p_; return v; }
             for (;;) {
@@ -70,6 +94,7 @@ private:
                 err("expected ',' or '}'");
             }
         } else if (c == '[') {
+            Nest nest(*this);
             v.kind = JsonValue::Array; ++p_; ws();
             if (p_ < s_.size() && s_[p_] == ']') { ++p_; return v; }
             for (;;) {
@@ -85,10 +110,10 @@ private:
         } else if (lit("false")) { v.kind = JsonValue::Bool; v.b = false;
         } else if (lit("null")) { v.kind = JsonValue::Null;
         } else if (c == '-' || (c >= '0' && c <= '9')) {
-            const char* start = s_.c_str() + p_; char* end = nullptr;
-            v.kind = JsonValue::Number; v.num = std::strtod(start, &end);
-            if (end == start) err("bad number");
-            p_ += (size_t)(end - start);
+            const size_t q = number_end(v.integral);
+            if (q == p_) err("bad number");
+            v.kind = JsonValue::Number; v.num = std::strtod(s_.substr(p_, q - p_).c_str(), nullptr);
+            p_ = q;
         } else err("unexpected character");
         return v;
     }

@@ -26,35 +26,49 @@ static bool make_triangle(V3 v0, V3 v1, V3 v2, mi355rt_triangle& out) {
     return !(dot(c, c) < EPSILON * EPSILON);
 }
 
+// Malformed input fails the whole mesh, as `tobj::load_obj(..)?` does (mesh_object.rs:64): a `v` line without three
+// floats (tobj PositionParseError), a face corner that is not an integer (FaceParseError) or that points outside the
+// vertices read so far (FaceVertexOutOfBounds), an index stream that is not a multiple of 3 after triangulation --
+// points and lines stay 1 / 2 indices -- (mesh_object.rs:98-104), and a file without any face (:67-69).
 int load_obj(const std::string& path, std::vector<mi355rt_triangle>& tris) {
     std::ifstream f(path);
     if (!f) return set_error(MI355RT_ERR_IO, "cannot open OBJ " + path);
     std::vector<V3> verts;
     std::vector<long> face;
     std::string line;
+    size_t line_no = 0, n_faces = 0, n_indices = 0;
+    auto at = [&](const char* what) { return set_error(MI355RT_ERR_IO, std::string("OBJ ") + path + ":" + std::to_string(line_no) + ": " + what); };
     while (std::getline(f, line)) {
+        ++line_no;
         const char* s = line.c_str();
         while (*s == ' ' || *s == '\t') ++s;
         if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
             double x = 0, y = 0, z = 0;
-            if (std::sscanf(s + 1, "%lf %lf %lf", &x, &y, &z) == 3) verts.push_back({(float)x, (float)y, (float)z});
+            if (std::sscanf(s + 1, "%lf %lf %lf", &x, &y, &z) != 3) return at("vertex position needs three numbers");
+            verts.push_back({(float)x, (float)y, (float)z});
         } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
             face.clear();
             std::istringstream ss(s + 1);
             std::string tok;
             while (ss >> tok) {
-                long i = std::strtol(tok.c_str(), nullptr, 10);            // "a", "a/b", "a/b/c", "a//c"
-                face.push_back(i > 0 ? i - 1 : (long)verts.size() + i);
+                char* end = nullptr;
+                const long i = std::strtol(tok.c_str(), &end, 10);         // "a", "a/b", "a/b/c", "a//c"
+                if (end == tok.c_str() || (*end != 0 && *end != '/')) return at("face corner is not an index");
+                const long v = i > 0 ? i - 1 : (long)verts.size() + i;
+                if (i == 0 || v < 0 || v >= (long)verts.size()) return at("face corner index out of bounds");
+                face.push_back(v);
             }
+            if (face.empty()) return at("face without corners");
+            ++n_faces;
+            n_indices += face.size() >= 3 ? 3 * (face.size() - 2) : face.size();
             for (size_t k = 1; k + 1 < face.size(); ++k) {
-                const long a = face[0], b = face[k], c = face[k + 1];
-                const long n = (long)verts.size();
-                if (a < 0 || b < 0 || c < 0 || a >= n || b >= n || c >= n) continue;   // mesh_object.rs:114-119
                 mi355rt_triangle t;
-                if (make_triangle(verts[a], verts[b], verts[c], t)) tris.push_back(t);
+                if (make_triangle(verts[face[0]], verts[face[k]], verts[face[k + 1]], t)) tris.push_back(t);
             }
         }
     }
+    if (n_faces == 0) return set_error(MI355RT_ERR_IO, "No models found in OBJ file: " + path);
+    if (n_indices % 3 != 0) return set_error(MI355RT_ERR_IO, "Invalid index data length in OBJ file: " + path);
     return MI355RT_OK;
 }
 

@@ -40,6 +40,13 @@ struct ParseError { std::string msg; };
 [[noreturn]] void bad(const std::string& m) { throw ParseError{m}; }
 
 float num_f32(const JsonValue& v) { if (!v.is_number()) bad("expected a number"); return (float)v.num; }
+// serde's `usize` fields (parser.rs:64-74,169-177): a non-negative JSON integer token -- 1.5, 1.0, 1e3 and -1 are
+// "invalid type" errors there, not truncations.  The C ABI carries these as u32, so larger values are refused too.
+uint32_t num_usize(const JsonValue& v, const char* what) {
+    if (!v.is_number() || !v.integral) bad(std::string("invalid type for `") + what + "`: expected usize");
+    if (!(v.num >= 0.0 && v.num <= 4294967295.0)) bad(std::string("`") + what + "` is out of range (this build carries it as u32)");
+    return (uint32_t)v.num;
+}
 
 // Vec3Config (parser.rs:23-28): derived struct -> serde accepts {"x","y","z"} or a 3-sequence
 V3 vec3cfg(const JsonValue& v) {
@@ -208,12 +215,14 @@ void load_impl(const std::string& json_path, const mi355rt_load_overrides* ov, m
     const JsonValue* cam = cfg.get("camera");
     if (!cam || !cam->is_object()) bad("missing field `camera`");
     if (const JsonValue* res = cam->opt("resolution")) {
-        if (res->is_number()) width = height = (uint32_t)res->num;
-        else if (res->is_array() && res->arr.size() == 2) { width = (uint32_t)num_f32(res->arr[0]); height = (uint32_t)num_f32(res->arr[1]); }
-        else bad("camera.resolution");
+        if (res->is_number()) width = height = num_usize(*res, "camera.resolution");                    // ResolutionConfig::Square
+        else if (res->is_array()) {                                                                       // ::Explicit(Vec<usize>): any length parses,
+            std::vector<uint32_t> a; for (const JsonValue& e : res->arr) a.push_back(num_usize(e, "camera.resolution[]"));
+            if (a.size() == 2) { width = a[0]; height = a[1]; }                                           // only len 2 is used (parser.rs:266-271)
+        } else bad("camera.resolution: data did not match any variant of untagged enum ResolutionConfig");
     }
-    if (const JsonValue* r = cfg.opt("renderer")) if (const JsonValue* s = r->opt("spp")) spp = (uint32_t)num_f32(*s);
-    if (const JsonValue* i = cfg.opt("integrator")) if (const JsonValue* m = i->opt("max_bounces")) max_depth = (uint32_t)num_f32(*m);
+    if (const JsonValue* r = cfg.opt("renderer")) if (const JsonValue* s = r->opt("spp")) spp = num_usize(*s, "renderer.spp");
+    if (const JsonValue* i = cfg.opt("integrator")) if (const JsonValue* m = i->opt("max_bounces")) max_depth = num_usize(*m, "integrator.max_bounces");
     if (ov) {
         if (ov->width) width = ov->width;
         if (ov->height) height = ov->height;

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, SCENES, pkg
 
 
-def _worker(rank, world, port, strip_rows, out_path, W, H):
+def _worker(rank, world, port, strip_rows, out_path, W, H, collective="all_gather"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,7 +29,7 @@ def _worker(rank, world, port, strip_rows, out_path, W, H):
     assert packed.shape[0] == len(plan.rows[rank])
     local = torch.zeros((plan.max_rows, W), dtype=torch.int32)
     local[:packed.shape[0]] = torch.from_numpy(packed.astype(np.int32))
-    img = rtdist.gather_image(local, plan, rank)
+    img = rtdist.gather_image(local, plan, rank, collective=collective)
     if rank == 0:
         np.save(out_path, img.numpy().astype(np.uint32))
     else:
@@ -45,6 +45,20 @@ def test_two_rank_gather_is_bit_identical(strip_rows, H, tmp_path, oracle_mod, a
     out = str(tmp_path / "img.npy")
     port = 29500 + (os.getpid() + strip_rows * 7 + H) % 2000
     mp.spawn(_worker, args=(2, port, strip_rows, out, W, H), nprocs=2, join=True)
+    got = np.load(out)
+    sc = scene_loader.load_scene(SCENES["cornell"], width=W, height=H, spp=2, max_depth=4)
+    want, _, _ = oracle_mod.render(sc, sc.camera, sc.settings, abi.Options.make(), threads=1, want_linear=False)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,collective", [(2, "gather"), (8, "all_gather")])
+def test_rooted_gather_and_the_eight_rank_plan(world, collective, tmp_path, oracle_mod, abi):
+    """The 8-GPU decomposition of the bench (strip plan chosen by make_plan itself) with 8 gloo ranks, and the rooted-gather form."""
+    from oracle import scene_loader
+    W, H = 8, 40
+    out = str(tmp_path / "img.npy")
+    port = 31500 + (os.getpid() + world) % 2000
+    mp.spawn(_worker, args=(world, port, None, out, W, H, collective), nprocs=world, join=True)
     got = np.load(out)
     sc = scene_loader.load_scene(SCENES["cornell"], width=W, height=H, spp=2, max_depth=4)
     want, _, _ = oracle_mod.render(sc, sc.camera, sc.settings, abi.Options.make(), threads=1, want_linear=False)

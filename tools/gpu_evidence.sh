@@ -1,0 +1,19 @@
+#!/bin/bash
+# Full evidence pass on the GPU box (run through gpurun): gpu tests, one bench line per BASELINE config, the rocprofv3
+# kernel-trace summary of the headline command and the PMC passes bench.py's roofline is computed from.
+# usage: tools/gpu_evidence.sh <tag>   -> everything under gpurun_out/<tag>/
+set -u -o pipefail
+TAG=${1:-ev}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+python3 -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1 || { tail -30 "$OUT/pytest_gpu.log"; exit 1; }
+tail -3 "$OUT/pytest_gpu.log"
+python3 tools/pmc_collect.py --out "$OUT/pmc" > "$OUT/pmc_collect.log" 2>&1 || { tail -30 "$OUT/pmc_collect.log"; exit 1; }
+cp "$OUT/pmc/pmc_counters.json" profiles/pmc_counters.json
+for WL in cornell-box-800x600x256-d30 teapot-800x600x256-d64 veach-mis-1280x720x1024-d16 semesterbild-800x600x256-d30; do
+  python3 bench.py --workload $WL --tail-parts 8 > "$OUT/bench_$WL.json" 2> "$OUT/bench_$WL.err" || { cat "$OUT/bench_$WL.err"; exit 1; }
+  echo "$WL done"
+done
+python3 bench.py --workload semesterbild-1920x1080x4096-d30 --steps 3 --warmup 1 > "$OUT/bench_semesterbild-1920x1080x4096-d30.json" 2> "$OUT/bench_cfg5.err" || { cat "$OUT/bench_cfg5.err"; exit 1; }
+python3 bench.py --pipeline 2 --cpu-seconds 0 > "$OUT/bench_cornell_pipeline2.json" 2>&1 || { cat "$OUT/bench_cornell_pipeline2.json"; exit 1; }
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/stats" -- python3 "$OLDPWD/bench.py" --steps 20 --warmup 3 --cpu-seconds 0 > "$OLDPWD/$OUT/stats.log" 2>&1) || { tail -20 "$OUT/stats.log"; exit 1; }
+find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_cornell.csv" \;
+cat "$OUT/bench_cornell-box-800x600x256-d30.json"
