@@ -58,6 +58,34 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """Cores this job may really use: the scheduler affinity, cut down to the cgroup CPU quota when there is one (a GPU box
+    shows all of the host's cores to every tenant but gives each a share: 256 visible, 16 granted -- 256 threads on a 16-core
+    quota ran the oracle at HALF the 16-thread rate).  MI355RT_CPU_THREADS overrides."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    why = f"sched affinity {n}"
+    env = os.environ.get("MI355RT_CPU_THREADS")
+    if env:
+        return max(1, int(env)), f"MI355RT_CPU_THREADS={env}"
+    quota = None
+    try:                                                     # cgroup v2
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        try:                                                 # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    if quota is not None and quota < n:
+        n = max(1, int(quota + 0.5))
+        why += f", cgroup quota {quota:.1f}"
+    return n, why
+
+
 def load_pmc(workload, kernel_hash):
     """Counters of the dominant kernel per STEP (all bands of one full render) for `workload`, or the reason there are none."""
     if not os.path.exists(PMC_FILE):
@@ -173,7 +201,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_image = image
+    torch.cuda.synchronize()
+    image_checksum = None if image is None else int(image.to(torch.int64).sum().item())    # identical for every N and pipeline depth (RNG keyed by absolute row)
+    final_image = None if image is None else image.clone()                                  # the slot buffers are reused below
 
     # one extra (untimed) step with counters for rays/sample
     torch.cuda.synchronize()
@@ -250,8 +280,8 @@ def main():
             **({"rehearsal": "all ranks on cuda:0 over gloo -- plumbing check only, NOT a measurement"} if rehearse else {}),
             "kernel": {"vgprs": st.kernel_vgprs, "grid_blocks": st.grid_blocks, "block_threads": st.block_threads, "bands": st.bands},
         }
-        if final_image is not None:
-            result["image_checksum"] = int(final_image.to(torch.int64).sum().item())      # identical for every N and pipeline depth (RNG keyed by absolute row)
+        if image_checksum is not None:
+            result["image_checksum"] = image_checksum
         if args.save_png and final_image is not None:
             import numpy as np
             host.write_png(args.save_png, final_image.cpu().numpy().astype(np.uint32), W, H)
@@ -302,8 +332,8 @@ def run_cpu_baseline(abi, scene, W, H, spp, target_seconds):
     import oracle
     oracle.build()
     nproc = os.cpu_count() or 1
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc
-    threads = cores                                          # every core this process may run on
+    cores, why = usable_cores()
+    threads = cores                                          # every core this job may use
 
     def every(n_rows):
         n_rows = max(1, min(H, n_rows))
@@ -324,7 +354,7 @@ def run_cpu_baseline(abi, scene, W, H, spp, target_seconds):
     _, _, c = oracle.render(scene, scene.camera, sample_settings, opt, threads=threads, want_linear=False)
     rows = len(abi.rows_selected(H, opt))
     base = {"value": round(c.samples / c.seconds / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "nproc": nproc, "cpu_model": cpu_model(), "threads": threads,
+            "nproc": nproc, "cpu_model": cpu_model(), "threads": threads, "threads_rule": why,
             "sample": f"every {opt.n_parts}th row ({rows} of {H} rows = {rows / threads:.1f} per thread) at {s_spp} of {spp} spp, {c.samples} samples, {c.seconds:.1f} s; "
                       "same scene/resolution/depth; C++ restatement of the reference's rayon path with its ChaCha12 row streams",
             "rays_per_sample": round(c.rays / max(c.samples, 1), 4)}

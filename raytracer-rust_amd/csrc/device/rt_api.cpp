@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -89,7 +90,7 @@ struct mi355rt_context {
     mi355rt_settings settings{};
     DevCamera cam{};
     float miss[3] = {0.5f, 0.5f, 0.5f};
-    uint32_t n_prims = 0, n_mats = 0;
+    uint32_t n_prims = 0, n_mats = 0; size_t n_nodes = 0;
     DevBuf<DevPrim> prims; DevBuf<DevMat> mats; DevBuf<DevNode> nodes; DevBuf<DevTri> tris;
     DevBuf<uint32_t> rows; DevBuf<float> radiance; DevBuf<uint32_t> counters; DevBuf<unsigned long long> stats;
     DevBuf<float> fold_stack;
@@ -116,54 +117,142 @@ struct mi355rt_context {
 
 namespace {
 
-// Re-lay one mesh's BVH (any node order, explicit child indices -- the shape of BVHNode, bvh.rs:7-12)
-// into the threaded pre-order form the kernel walks, and its triangles into leaf order.
-int flatten_mesh(const mi355rt_scene* sc, const mi355rt_mesh& m, std::vector<DevNode>& out_nodes, std::vector<DevTri>& out_tris,
-                 uint32_t& node_begin, uint32_t& node_end) {
+// Re-lay the meshes' BVHs (any node order, explicit child indices -- the shape of BVHNode, bvh.rs:7-12) into the
+// two-link form the kernels walk (rt_device.h, DevNode): every node carries where the walk goes when its box is hit
+// (inner: the left child, bvh.rs:142) and where it goes otherwise / afterwards (the "escape": the next node of the
+// reference's left-then-right recursion that is not below this one).  The links make the visit order independent of
+// the storage order, so nodes are stored LEVEL BY LEVEL (level 0 of every mesh, then level 1, ...): the levels every
+// ray touches come first and are the part the state-machine kernel keeps in LDS.  Triangles go into leaf-visit order.
+struct MeshFlat {
+    std::vector<uint32_t> order;                 // input node ids in BFS order
+    std::vector<uint32_t> level_begin;           // order[level_begin[L] .. level_begin[L+1]) = level L
+    std::vector<uint32_t> escape;                // per input node: input id of its escape node, NODE_END if none
+    std::vector<uint32_t> first_tri;             // per input leaf: index of its first triangle in out_tris
+    std::vector<uint32_t> global_id;             // per input node: index in the device array
+};
+
+int flatten_mesh(const mi355rt_scene* sc, const mi355rt_mesh& m, MeshFlat& f, std::vector<DevTri>& out_tris) {
     if ((uint64_t)m.first_triangle + m.triangle_count > sc->n_triangles || m.triangle_count == 0) return fail(MI355RT_ERR_INVALID, "mesh triangle range");
     if ((uint64_t)m.first_node + m.node_count > sc->n_nodes || m.node_count == 0) return fail(MI355RT_ERR_INVALID, "mesh node range (is the BVH missing? see mi355rt_bvh_build)");
     if ((uint64_t)m.first_index + m.index_count > sc->n_tri_indices) return fail(MI355RT_ERR_INVALID, "mesh index range");
     const mi355rt_bvh_node* nodes = sc->nodes + m.first_node;
     const uint32_t* indices = sc->tri_indices + m.first_index;
     const mi355rt_triangle* tris = sc->triangles + m.first_triangle;
-    node_begin = (uint32_t)out_nodes.size();
-    // iterative pre-order with an explicit stack of (node, fixup slot) -- input depth is not trusted
-    std::vector<uint32_t> stack;         // nodes still to visit (right children)
-    std::vector<std::pair<uint32_t, uint32_t>> open;   // (output index of inner node, remaining children)
+    f.escape.assign(m.node_count, NODE_END); f.first_tri.assign(m.node_count, 0u); f.global_id.assign(m.node_count, NODE_END);
+    // pre-order with an explicit stack (input depth is not trusted): escapes, leaf-order triangles, cycle check
+    std::vector<uint8_t> seen(m.node_count, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> stack;   // (node, its escape)
+    stack.emplace_back(0u, NODE_END);
     uint32_t visited = 0;
-    stack.push_back(0);
     while (!stack.empty()) {
-        uint32_t ni = stack.back(); stack.pop_back();
+        const auto [ni, esc] = stack.back(); stack.pop_back();
         if (ni >= m.node_count) return fail(MI355RT_ERR_INVALID, "BVH child index out of range");
-        if (++visited > m.node_count) return fail(MI355RT_ERR_INVALID, "BVH has a cycle or shared nodes");
+        if (seen[ni] || ++visited > m.node_count) return fail(MI355RT_ERR_INVALID, "BVH has a cycle or shared nodes");
+        seen[ni] = 1;
+        f.escape[ni] = esc;
         const mi355rt_bvh_node& n = nodes[ni];
-        DevNode d;
-        std::memcpy(d.bmin, n.bmin, 12); std::memcpy(d.bmax, n.bmax, 12);
-        const uint32_t my = (uint32_t)out_nodes.size();
         if (n.index_count > 0) {
             if ((uint64_t)n.first_index + n.index_count > m.index_count) return fail(MI355RT_ERR_INVALID, "BVH leaf index range");
-            d.a = (uint32_t)out_tris.size(); d.b = n.index_count;
+            f.first_tri[ni] = (uint32_t)out_tris.size();
             for (uint32_t k = 0; k < n.index_count; ++k) {
-                uint32_t id = indices[n.first_index + k];
+                const uint32_t id = indices[n.first_index + k];
                 if (id >= m.triangle_count) return fail(MI355RT_ERR_INVALID, "BVH leaf triangle id out of range");
                 const mi355rt_triangle& t = tris[id];
                 DevTri dt;
                 for (int c = 0; c < 3; ++c) { dt.v0[c] = t.v0[c]; dt.e1[c] = t.v1[c] - t.v0[c]; dt.e2[c] = t.v2[c] - t.v0[c]; dt.n[c] = t.normal[c]; }
                 out_tris.push_back(dt);
             }
-            out_nodes.push_back(d);
-            // a finished leaf closes every inner node whose last child it was
-            while (!open.empty() && --open.back().second == 0) { out_nodes[open.back().first].a = (uint32_t)out_nodes.size(); open.pop_back(); }
         } else {
-            d.a = 0; d.b = 0;
-            out_nodes.push_back(d);
-            open.emplace_back(my, 2u);
-            stack.push_back(n.right);     // visited after the whole left subtree
-            stack.push_back(n.left);
+            stack.emplace_back(n.right, esc);        // visited after the whole left subtree; it inherits the parent's escape
+            stack.emplace_back(n.left, n.right);     // a left child escapes to its sibling
         }
     }
-    if (!open.empty()) return fail(MI355RT_ERR_INVALID, "BVH malformed");
-    node_end = (uint32_t)out_nodes.size();
+    // breadth-first order
+    f.order.clear(); f.level_begin.clear();
+    f.order.push_back(0u); f.level_begin.push_back(0u);
+    for (size_t lb = 0; lb < f.order.size();) {
+        const size_t le = f.order.size();
+        for (size_t i = lb; i < le; ++i) {
+            const mi355rt_bvh_node& n = nodes[f.order[i]];
+            if (n.index_count == 0) { f.order.push_back(n.left); f.order.push_back(n.right); }
+        }
+        lb = le;
+        if (f.order.size() > le) f.level_begin.push_back((uint32_t)le);
+    }
+    f.level_begin.push_back((uint32_t)f.order.size());
+    return MI355RT_OK;
+}
+
+int flatten_meshes(const mi355rt_scene* sc, std::vector<DevNode>& out_nodes, std::vector<DevTri>& out_tris, std::vector<uint32_t>& roots) {
+    std::vector<MeshFlat> flat(sc->n_meshes);
+    size_t max_levels = 0, total = 0;
+    for (uint32_t m = 0; m < sc->n_meshes; ++m) {
+        int rc = flatten_mesh(sc, sc->meshes[m], flat[m], out_tris);
+        if (rc) return rc;
+        max_levels = std::max(max_levels, flat[m].level_begin.size() - 1);
+        total += flat[m].order.size();
+    }
+    // the walk packs node indices into 26 bits (and addresses nodes / triangles with 32-bit byte offsets)
+    if (total >= NODE_END || out_tris.size() > (1u << 26)) return fail(MI355RT_ERR_INVALID, "more than 2^26 BVH nodes or triangles");
+    // Storage order: breadth-first, level by level across all meshes, until the LDS copy is full (LDS_NODE_CAP nodes: the
+    // levels every ray touches); every subtree hanging below that front then follows in depth-first pre-order, so that a
+    // walk through the global-memory part finds a node's left child right behind it (same or next cache line).
+    uint32_t next = 0;
+    for (size_t L = 0; L < max_levels && next < LDS_NODE_CAP; ++L)
+        for (uint32_t m = 0; m < sc->n_meshes && next < LDS_NODE_CAP; ++m) {
+            MeshFlat& f = flat[m];
+            if (L + 1 >= f.level_begin.size()) continue;
+            for (uint32_t i = f.level_begin[L]; i < f.level_begin[L + 1] && next < LDS_NODE_CAP; ++i) f.global_id[f.order[i]] = next++;
+        }
+    for (uint32_t m = 0; m < sc->n_meshes; ++m) {
+        MeshFlat& f = flat[m];
+        const mi355rt_bvh_node* nodes = sc->nodes + sc->meshes[m].first_node;
+        std::vector<uint32_t> stack;
+        for (uint32_t ni : f.order) {                                   // BFS order: parents before children
+            if (f.global_id[ni] != NODE_END) continue;
+            // ni is the root of an unplaced subtree (its parent was placed, or it is a mesh root beyond the cap)
+            stack.assign(1, ni);
+            while (!stack.empty()) {
+                const uint32_t x = stack.back(); stack.pop_back();
+                f.global_id[x] = next++;
+                if (nodes[x].index_count == 0) { stack.push_back(nodes[x].right); stack.push_back(nodes[x].left); }
+            }
+        }
+    }
+    out_nodes.assign(total, DevNode{});
+    roots.assign(sc->n_meshes, 0u);
+    for (uint32_t m = 0; m < sc->n_meshes; ++m) {
+        const MeshFlat& f = flat[m];
+        const mi355rt_bvh_node* nodes = sc->nodes + sc->meshes[m].first_node;
+        roots[m] = f.global_id[0];
+        for (uint32_t ni : f.order) {
+            const mi355rt_bvh_node& n = nodes[ni];
+            DevNode& d = out_nodes[f.global_id[ni]];
+            std::memcpy(d.bmin, n.bmin, 12); std::memcpy(d.bmax, n.bmax, 12);
+            const uint32_t esc = f.escape[ni] == NODE_END ? NODE_END : f.global_id[f.escape[ni]];
+            if (n.index_count == 0) { d.a = f.global_id[n.left]; d.b = esc; }
+            else if (n.index_count <= NODE_MAX_LEAF) { d.a = f.first_tri[ni]; d.b = esc | (n.index_count << NODE_LINK_BITS); }
+            else {
+                // A leaf with more triangles than the count field holds (BVHNode::new makes them only at depth 25, bvh.rs:31;
+                // a caller-built tree may have them anywhere): its box test stays where it is, as an inner node whose "left
+                // child" is a chain of chunk leaves with infinite bounds.  An infinite box is hit by every ray (the slab test
+                // leaves t_min / t_max untouched), so the chain only adds box tests that change nothing; a miss of the real
+                // box skips the whole chain.  The chunks live behind the level-ordered part of the array.
+                d.a = (uint32_t)out_nodes.size(); d.b = esc;
+                const float inf = std::numeric_limits<float>::infinity();
+                for (uint32_t k = 0; k < n.index_count; k += NODE_MAX_LEAF) {
+                    const uint32_t cnt = std::min(NODE_MAX_LEAF, n.index_count - k);
+                    const bool last = k + cnt == n.index_count;
+                    DevNode c;
+                    for (int x = 0; x < 3; ++x) { c.bmin[x] = -inf; c.bmax[x] = inf; }
+                    c.a = f.first_tri[ni] + k;
+                    c.b = (last ? esc : (uint32_t)out_nodes.size() + 1u) | (cnt << NODE_LINK_BITS);
+                    out_nodes.push_back(c);       // may reallocate: `d` is not used after this loop
+                }
+            }
+        }
+    }
+    if (out_nodes.size() >= NODE_END) return fail(MI355RT_ERR_INVALID, "more than 2^26 BVH nodes");
     return MI355RT_OK;
 }
 
@@ -202,14 +291,9 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     for (uint32_t i = 0; i < sc->n_materials; ++i)
         if (sc->materials[i].kind >= MI355RT_MAT_KIND_COUNT) return fail(MI355RT_ERR_INVALID, "material kind");
 
-    std::vector<DevNode> nodes; std::vector<DevTri> tris;
-    std::vector<std::pair<uint32_t, uint32_t>> mesh_ranges(sc->n_meshes);
-    for (uint32_t m = 0; m < sc->n_meshes; ++m) {
-        int rc = flatten_mesh(sc, sc->meshes[m], nodes, tris, mesh_ranges[m].first, mesh_ranges[m].second);
-        if (rc) return rc;
-    }
-    // the BVH walk addresses nodes and triangles with 32-bit byte offsets (node * 32, triangle * 48)
-    if (nodes.size() > (1u << 26) || tris.size() > (1u << 26)) return fail(MI355RT_ERR_INVALID, "more than 2^26 BVH nodes or triangles");
+    std::vector<DevNode> nodes; std::vector<DevTri> tris; std::vector<uint32_t> mesh_roots;
+    if (sc->n_meshes && (!sc->meshes || !sc->nodes || !sc->triangles || (!sc->tri_indices && sc->n_tri_indices))) return fail(MI355RT_ERR_INVALID, "mesh arrays are null");
+    { int rc = flatten_meshes(sc, nodes, tris, mesh_roots); if (rc) return rc; }
     std::vector<DevPrim> prims(sc->n_primitives);
     for (uint32_t i = 0; i < sc->n_primitives; ++i) {
         const mi355rt_primitive& p = sc->primitives[i];
@@ -228,7 +312,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
             if (p.kind == MI355RT_PRIM_CUBE) cube_normal_table(d.d);
             if (p.kind == MI355RT_PRIM_MESH) {
                 if (p.mesh >= sc->n_meshes) return fail(MI355RT_ERR_INVALID, "primitive mesh index");
-                d.node_begin = mesh_ranges[p.mesh].first; d.node_end = mesh_ranges[p.mesh].second;
+                d.node_begin = mesh_roots[p.mesh]; d.node_end = 0;
             }
         } else {
             std::memcpy(d.d, p.data, 32 * sizeof(float));
@@ -244,7 +328,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     if (sc->n_materials) HIP_TRY(hipMemcpy(ctx->mats.p, sc->materials, sc->n_materials * sizeof(DevMat), hipMemcpyHostToDevice));
     if (!nodes.empty()) HIP_TRY(hipMemcpy(ctx->nodes.p, nodes.data(), nodes.size() * sizeof(DevNode), hipMemcpyHostToDevice));
     if (!tris.empty()) HIP_TRY(hipMemcpy(ctx->tris.p, tris.data(), tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
-    ctx->n_prims = sc->n_primitives; ctx->n_mats = sc->n_materials;
+    ctx->n_prims = sc->n_primitives; ctx->n_mats = sc->n_materials; ctx->n_nodes = nodes.size();
     std::memcpy(ctx->miss, sc->miss_color, 12);
     ctx->sky_w = ctx->sky_h = 0;
     if (has_sky) {
@@ -433,12 +517,13 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.sample0 = s0;
         magic_div((uint32_t)spp, p.spp_mul, p.spp_shift); magic_div(st.width, p.width_mul, p.width_shift);
         p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;
+        p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, LDS_NODE_CAP);
         ResolveParams r{};
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
         r.spp = (uint32_t)spp; r.inv_spp = 1.0f / (float)s1;                             // renderer.rs:85
         r.accum = (float*)d_accum; r.accum_load = s0 != 0 ? 1u : 0u;
         const uint32_t resident = (uint32_t)(ctx->cu_count * ctx->blocks_per_cu[variant]);
-        block_threads = BLOCK_THREADS;
+        block_threads = block_threads_of(variant);
         std::vector<float> band_ms;
         for (uint32_t b = 0; b < n_bands; ++b) {
             const uint64_t p0 = (uint64_t)b * band_pixels_max;
@@ -446,7 +531,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             p.band_pixel0 = (uint32_t)p0; p.band_samples = (uint32_t)(np * spp);
             p.batch_counter = ctx->counters.p + (size_t)b * ctr_words;
             p.shard_samples = (p.band_samples + WORK_SHARDS - 1) / WORK_SHARDS;
-            const uint32_t waves_per_block = BLOCK_THREADS / 64;
+            const uint32_t waves_per_block = block_threads / 64;
             const uint32_t min_runs = (p.band_samples + BATCH_MIN - 1) / BATCH_MIN;           // never more waves than minimum-size runs
             const uint32_t grid = std::max(1u, std::min(resident, (min_runs + waves_per_block - 1) / waves_per_block));
             p.guided_div = std::max(1u, ctx->guided_mult * grid * waves_per_block / WORK_SHARDS);
@@ -526,6 +611,38 @@ int mi355rt_debug_read_wave_times(mi355rt_context* ctx, unsigned long long* out,
     if (n) HIP_TRY(hipMemcpy(out, ctx->wave_times.p, (size_t)n * WAVE_TIME_WORDS * 8, hipMemcpyDeviceToHost));
     *n_waves = n;
     return MI355RT_OK;
+}
+
+// Diagnostic hooks (not part of the public header): one Material::scatter / one HittableList::hit per record through the
+// device functions of the render kernels, on the context's resident scene.  Host pointers in and out; records are the
+// 16- / 6- / 12-word PODs of rt_device.h.
+int mi355rt_debug_scatter(mi355rt_context* ctx, const void* in_records, uint32_t n, void* out_records) {
+    if (!ctx || !ctx->have_scene || !in_records || !out_records) return fail(MI355RT_ERR_INVALID, "debug_scatter: null / no scene");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const DebugScatterIn* in = static_cast<const DebugScatterIn*>(in_records);
+    for (uint32_t i = 0; i < n; ++i) if (in[i].material >= ctx->n_mats) return fail(MI355RT_ERR_INVALID, "debug_scatter: material index");
+    DevBuf<DebugScatterIn> d_in; DevBuf<DebugScatterOut> d_out;
+    int rc = d_in.ensure(n); if (!rc) rc = d_out.ensure(n);
+    if (!rc && n) {
+        if (hipMemcpy(d_in.p, in, n * sizeof(DebugScatterIn), hipMemcpyHostToDevice) != hipSuccess || launch_debug_scatter(ctx->mats.p, d_in.p, d_out.p, n, nullptr) != 0 ||
+            hipMemcpy(out_records, d_out.p, n * sizeof(DebugScatterOut), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI355RT_ERR_HIP, "debug_scatter");
+    }
+    d_in.release(); d_out.release();
+    return rc;
+}
+
+int mi355rt_debug_hit(mi355rt_context* ctx, const void* in_rays, uint32_t n, void* out_records) {
+    if (!ctx || !ctx->have_scene || !in_rays || !out_records) return fail(MI355RT_ERR_INVALID, "debug_hit: null / no scene");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<DebugHitIn> d_in; DevBuf<DebugHitOut> d_out;
+    int rc = d_in.ensure(n); if (!rc) rc = d_out.ensure(n);
+    if (!rc && n) {
+        if (hipMemcpy(d_in.p, in_rays, n * sizeof(DebugHitIn), hipMemcpyHostToDevice) != hipSuccess ||
+            launch_debug_hit(ctx->prims.p, ctx->n_prims, ctx->nodes.p, ctx->tris.p, d_in.p, d_out.p, n, nullptr) != 0 ||
+            hipMemcpy(out_records, d_out.p, n * sizeof(DebugHitOut), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI355RT_ERR_HIP, "debug_hit");
+    }
+    d_in.release(); d_out.release();
+    return rc;
 }
 
 int mi355rt_context_set_timing(mi355rt_context* ctx, int enable) {

@@ -6,9 +6,12 @@
 //   DevPrim[n_prims]   224 B  top-level list in caller order (hittable.rs:45-58), read through the
 //                             constant address space with a wave-uniform index -> SGPRs
 //   DevMat[n_mats]      64 B  per-lane gather by material index (4 x dwordx4)
-//   DevNode[n_nodes]    32 B  per-mesh BVH in DFS pre-order ("threaded"): the left child of node i
-//                             is i+1; `a` is the escape index for inner nodes / first triangle for
-//                             leaves, `b` is 0 for inner nodes / triangle count for leaves
+//   DevNode[n_nodes]    32 B  two-link BVH nodes, stored level by level (all meshes' roots, then their children, ...):
+//                             `b` = escape index (bits 0..25; NODE_END ends the walk) | leaf triangle count << 26
+//                             (0: inner node); `a` = left child (inner) / first triangle (leaf).  Hit inner -> a,
+//                             hit leaf -> its triangles then the escape, miss -> the escape: exactly the
+//                             left-then-right order of bvh.rs:142-156, whatever the storage order.  The first
+//                             LDS_NODE_CAP nodes (the top levels) are what k_render_ctr_sm keeps in LDS
 //   DevTri[n_tris]      48 B  triangles re-ordered into leaf order, stored as v0, e1=v1-v0, e2=v2-v0,
 //                             normal (the same f32 subtractions bvh.rs:95-96 performs per test)
 //   rows[n_rows]         4 B  local output row -> absolute image row y (the RNG key)
@@ -40,6 +43,12 @@ static_assert(sizeof(DevMat) == 64, "DevMat");
 
 struct DevNode { float bmin[3]; uint32_t a; float bmax[3]; uint32_t b; };
 static_assert(sizeof(DevNode) == 32, "DevNode");
+constexpr uint32_t NODE_LINK_BITS = 26;
+constexpr uint32_t NODE_END = (1u << NODE_LINK_BITS) - 1u;       // escape link of the last nodes of a walk
+constexpr uint32_t NODE_MAX_LEAF = 63;                           // triangles per leaf record (6-bit count); fatter leaves become chunk chains
+// LDS copy of the hot top of the node array in the state-machine kernel: one 1024-thread workgroup per CU owns the
+// CU's whole 160 KiB (163 840 B); 5 104 nodes x 32 B = 163 328 B.
+constexpr uint32_t LDS_NODE_CAP = 5104;
 
 struct DevTri { float v0[3], e1[3], e2[3], n[3]; };
 static_assert(sizeof(DevTri) == 48, "DevTri");
@@ -55,7 +64,8 @@ struct DevCamera { float position[3], forward[3], right[3], true_up[3], half_wid
 // 256 = one pixel's samples at the headline 256 spp: the lanes of a wave then share the camera ray and the first
 // hit, so whole accept blocks are skipped wave-wide (measured: 2048 -> 27.1 ms, 512 -> 26.1, 256 -> 25.8 on cornell).
 constexpr uint32_t BATCH_MIN = MI355RT_BATCH_MIN, BATCH_MAX = MI355RT_BATCH_MAX;   // paths a wave claims per global atomic (guided self-scheduling)
-constexpr uint32_t BLOCK_THREADS = 256;
+constexpr uint32_t BLOCK_THREADS = 256;         // lockstep kernels
+constexpr uint32_t BLOCK_THREADS_SM = 1024;     // state-machine kernels: 16 waves = 4 per SIMD = one workgroup per CU, sharing the LDS node copy
 constexpr uint32_t WORK_SHARDS = 8;            // one work counter per XCD (power of two)
 constexpr uint32_t WORK_SHARD_STRIDE = 32;     // u32 words between counters: one 128-B line each
 constexpr uint32_t WAVE_TIME_WORDS = 6;        // diagnostic builds: per wave {start, end, paths, time work ran dry, iterations after, live lanes then}
@@ -81,6 +91,7 @@ struct RenderParams {
     uint32_t spp_mul, spp_shift, width_mul, width_shift;   // magic pairs for n / spp and n / width (n < 2^31)
     uint32_t trav_min;           // state-machine kernel: run BVH rounds while at least this many lanes are walking
     uint32_t inline_steps;       // state-machine kernel: box tests taken right at mesh setup (short walks skip the TRAV round trip)
+    uint32_t lds_nodes;          // state-machine kernel: nodes [0, lds_nodes) are read from the workgroup's LDS copy (<= LDS_NODE_CAP)
 };
 
 // Which counter-mode kernel serves a scene
@@ -117,10 +128,20 @@ struct RefParams {               // MI355RT_RNG_REF: one lane per selected row
     uint32_t seed_lo, seed_hi;
 };
 
+// Diagnostic per-function entry points (tests only; mi355rt_debug_scatter / mi355rt_debug_hit in rt_api.cpp): one record per lane
+// through exactly the device functions the render kernels call.
+struct DebugScatterIn { uint32_t material, front_face; float rd[3], p[3], n[3]; uint32_t k0, k1, x, s, ray; };     // 16 words
+struct DebugScatterOut { float scattered, o[3], d[3], atten[3], emitted[3], pad[3]; };                              // 16 words
+struct DebugHitIn { float o[3], d[3]; };                                                                            // d is normalised once (Ray::new)
+struct DebugHitOut { float p[3], n[3], t, material, front_face, hit, pad[2]; };                                     // 12 words
+int launch_debug_scatter(const DevMat* mats, const DebugScatterIn* in, DebugScatterOut* out, uint32_t n, void* stream);
+int launch_debug_hit(const DevPrim* prims, uint32_t n_prims, const DevNode* nodes, const DevTri* tris, const DebugHitIn* in, DebugHitOut* out, uint32_t n, void* stream);
+
 // launchers (rt_kernels.hip); `stream` is a hipStream_t
 int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blocks, void* stream);
 int launch_resolve(const ResolveParams& p, void* stream);
 int launch_render_ref(const RefParams& p, void* stream);
 int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs);
+inline uint32_t block_threads_of(uint32_t variant) { return (variant == 2u || variant == 4u) ? BLOCK_THREADS_SM : BLOCK_THREADS; }   // KERNEL_STATE_MACHINE*
 
 }  // namespace mi355rt

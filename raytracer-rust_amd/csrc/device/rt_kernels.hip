@@ -338,14 +338,15 @@ DI void finish_cube_hit(const DevPrim* __restrict__ prims, Hit& h, f3 rd_w) {
 DI bool hit_pending(const Hit& h) { return (h.mat_ff & 0xC0000000u) == HIT_PENDING_CUBE; }   // bit 31 is front_face of a finished record
 
 // mesh/mesh_object.rs:263-329 + acceleration/bvh.rs:78-170 + acceleration/aabb.rs:27-45.
-// Threaded pre-order walk; `best_t` plays the role of the recursion's shrinking t_max.  The walk is split
-// into setup / inner-node step / leaf / finalize so that the state-machine kernel can interleave the
-// traversals of different lanes; hit_mesh() composes them into the plain per-lane loop.
+// Stackless walk over two-link nodes (rt_device.h): hit inner -> left child, everything else -> the escape link, which
+// reproduces the reference's left-then-right recursion exactly; `best_t` plays the role of the recursion's shrinking
+// t_max.  The walk is split into setup / node step / leaf / finalize so that the state-machine kernel can interleave
+// the traversals of different lanes; hit_mesh() composes them into the plain per-lane loop.
 struct MeshTrav {
     f3 ro, rd;                 // object-space ray (direction normalised twice, mesh_object.rs:289)
     float ix, iy, iz;          // 1/d, aabb.rs:29 (same value at every node)
     float len_raw;             // |w2o * d_world| for the (sic) t_world formula
-    uint32_t node, end;        // pre-order cursor / one past the mesh's last node
+    uint32_t node;             // next node to visit; NODE_END: the walk is over
     float best_t; uint32_t best_tri;
     uint32_t leaf_a, leaf_b;   // pending leaf (first triangle, count); leaf_b == 0: none
 };
@@ -355,33 +356,49 @@ DI void mesh_setup(cprim_t pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {
     m.len_raw = len(rd_raw);
     m.rd = normalized(normalized(rd_raw));
     m.ix = 1.0f / m.rd.x; m.iy = 1.0f / m.rd.y; m.iz = 1.0f / m.rd.z;
-    m.node = pr->node_begin; m.end = pr->node_end;
+    m.node = pr->node_begin;
     m.best_t = t_max; m.best_tri = 0xFFFFFFFFu; m.leaf_b = 0; m.leaf_a = 0;
 }
-// Visit m.node (box test, aabb.rs:27-45).  Afterwards either m.node moved on, or a leaf is pending (m.leaf_b > 0).
+// Visit m.node (box test, aabb.rs:27-45).  Afterwards m.node is the next node to visit and, when a leaf was hit, its
+// triangles are pending (m.leaf_b > 0) and must be tested before the walk goes on.
 // FIXED_AABB: MI355RT_FLAG_FIXED_AABB -- a box is missed only when t_max < t_min (the reference misses on <=, aabb.rs:41).
-template <bool FIXED_AABB = false>
-DI void mesh_step(const float4* __restrict__ n4, float t_min, MeshTrav& m) {
+// USE_LDS: nodes below `lds_count` are read from the workgroup's LDS copy (ds_read_b128), the rest from global memory.
+typedef float lds_v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) lds_v4f* lds_nodes_t;
+template <bool FIXED_AABB = false, bool USE_LDS = false>
+DI void mesh_step(const float4* __restrict__ n4, lds_nodes_t lds, uint32_t lds_count, float t_min, MeshTrav& m) {
     // 32-bit byte offset from the uniform base: the load takes the base from SGPRs instead of a 64-bit per-lane address
-    // (node and triangle counts are validated against 2^26 at upload)
-    const float4* __restrict__ nq = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(n4) + (m.node << 5));
-    const float4 q0 = nq[0], q1 = nq[1];
+    // The choice between the LDS copy and global memory is made for the WAVE (the LDS copy is a copy: global memory holds every
+    // node): a per-lane choice would make the LDS readers wait for the other lanes' global loads (both paths fill the
+    // same registers) and serialise the two latencies.  Whole array in LDS (semesterbild): always the LDS path.
+    float4 q0, q1;
+    if (USE_LDS && __ballot(m.node >= lds_count) == 0ull) {
+        lds_nodes_t lq = reinterpret_cast<lds_nodes_t>(reinterpret_cast<const __attribute__((address_space(3))) char*>(lds) + (m.node << 5));
+        const lds_v4f l0 = lq[0], l1 = lq[1];
+        q0 = make_float4(l0.x, l0.y, l0.z, l0.w); q1 = make_float4(l1.x, l1.y, l1.z, l1.w);
+    } else {
+        const float4* __restrict__ nq = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(n4) + (m.node << 5));
+        q0 = nq[0]; q1 = nq[1];
+    }
     const uint32_t a = __float_as_uint(q0.w), b = __float_as_uint(q1.w);
+    // aabb.rs:31-44 returns false at the first axis whose interval is empty.  tmin only grows and tmax only shrinks from axis
+    // to axis (f32::max / f32::min ignore a NaN operand, so they never move the other way), hence an interval that is empty
+    // after some axis is still empty after the last one and vice versa: ONE test after the z axis decides the same.
     float tmin = t_min, tmax = m.best_t;
-    bool ok = true;
     {   float t0 = (q0.x - m.ro.x) * m.ix, t1 = (q1.x - m.ro.x) * m.ix; if (m.ix < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(FIXED_AABB ? (tmax < tmin) : (tmax <= tmin)); }
+        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); }
     {   float t0 = (q0.y - m.ro.y) * m.iy, t1 = (q1.y - m.ro.y) * m.iy; if (m.iy < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(FIXED_AABB ? (tmax < tmin) : (tmax <= tmin)); }
+        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); }
     {   float t0 = (q0.z - m.ro.z) * m.iz, t1 = (q1.z - m.ro.z) * m.iz; if (m.iz < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); ok = ok && !(FIXED_AABB ? (tmax < tmin) : (tmax <= tmin)); }
-    // Branch-free successor: missed inner node -> its escape index `a`; hit leaf -> stay, triangles pending; every other
-    // case (hit inner node: left child first; missed leaf: its successor) -> node + 1.
-    const bool inner = b == 0u, take_leaf = ok && !inner;
-    const uint32_t onward = (!ok && inner) ? a : m.node + 1u;
-    m.node = take_leaf ? m.node : onward;
+        tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1); }
+    const bool ok = !(FIXED_AABB ? (tmax < tmin) : (tmax <= tmin));
+    // Branch-free successor: hit inner node -> its left child `a`; missed node or leaf -> the escape link (a hit leaf's
+    // triangles are tested first: leaf_b > 0 holds the walk until mesh_leaf() has run).
+    const uint32_t count = b >> NODE_LINK_BITS, esc = b & NODE_END;
+    const bool take_leaf = ok && count != 0u;
+    m.node = (ok && count == 0u) ? a : esc;
     m.leaf_a = take_leaf ? a : m.leaf_a;
-    m.leaf_b = take_leaf ? b : m.leaf_b;
+    m.leaf_b = take_leaf ? count : m.leaf_b;
 }
 // Moeller-Trumbore over the pending leaf, bvh.rs:91-138
 DI void mesh_leaf(const float4* __restrict__ t4, float t_min, MeshTrav& m) {
@@ -401,7 +418,7 @@ DI void mesh_leaf(const float4* __restrict__ t4, float t_min, MeshTrav& m) {
         const bool hit = !(fabsf(aa) < EPS) && (u >= 0.0f && u <= 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > t_min && t < m.best_t);
         if (hit) { m.best_t = t; m.best_tri = m.leaf_a + k; }
     }
-    m.leaf_b = 0; m.node = m.node + 1;
+    m.leaf_b = 0;
 }
 DI bool mesh_finalize(cprim_t pr, const float4* __restrict__ t4, const MeshTrav& m, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h) {
     if (m.best_tri == 0xFFFFFFFFu) return false;
@@ -422,8 +439,8 @@ DI bool hit_mesh(cprim_t pr, const DevNode* __restrict__ nodes, const DevTri* __
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(nodes);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(tris);
     MeshTrav m; mesh_setup(pr, ro_w, rd_w, t_max, m);
-    while (m.node < m.end) {
-        mesh_step(n4, t_min, m);
+    while (m.node != NODE_END) {
+        mesh_step(n4, nullptr, 0u, t_min, m);
         if (m.leaf_b) mesh_leaf(t4, t_min, m);
     }
     return mesh_finalize(pr, t4, m, ro_w, rd_w, t_min, t_max, h);
@@ -949,6 +966,13 @@ DI void render_ctr_state_machine(const RenderParams& P) {
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
     const uint32_t lane = threadIdx.x & 63u;
+    // The workgroup (all 16 waves of the CU) copies the hot top of the node array -- the whole array when it fits -- into
+    // LDS once; from then on a box test costs two ds_read_b128 instead of two L2 round trips.
+    __shared__ float4 s_nodes[2u * LDS_NODE_CAP];
+    const uint32_t lds_count = P.lds_nodes;
+    for (uint32_t i = threadIdx.x; i < 2u * lds_count; i += blockDim.x) s_nodes[i] = n4[i];
+    __syncthreads();
+    lds_nodes_t lds = (lds_nodes_t)s_nodes;                       // explicit cast into the LDS address space: ds_read, not flat_load
     WorkCursor wc; wc.init();
     PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
     ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
@@ -956,12 +980,14 @@ DI void render_ctr_state_machine(const RenderParams& P) {
     bool walk_done = false;
     float closest = __builtin_inff(); bool any_hit = false;
     Hit best; best.t = 0.f; best.p = mk(0, 0, 0); best.n = mk(0, 0, 0); best.mat_ff = 0;
-    MeshTrav mt; mt.ro = mk(0, 0, 0); mt.rd = mk(0, 0, 1); mt.ix = mt.iy = mt.iz = 0.f; mt.len_raw = 0.f; mt.node = mt.end = 0; mt.best_t = 0.f;
+    MeshTrav mt; mt.ro = mk(0, 0, 0); mt.rd = mk(0, 0, 1); mt.ix = mt.iy = mt.iz = 0.f; mt.len_raw = 0.f; mt.node = NODE_END; mt.best_t = 0.f;
     mt.best_tri = 0xFFFFFFFFu; mt.leaf_a = mt.leaf_b = 0;
     uint32_t n_paths = 0, n_rays = 0;
     Prof prof; prof.begin();
     const uint32_t trav_min = P.trav_min;
 #ifdef MI355RT_STAMPS
+    const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_dry = 0ull; uint32_t drain_iters = 0, live_at_dry = 0;
     unsigned long long c_exec[4] = {0, 0, 0, 0}, c_lanes[4] = {0, 0, 0, 0};    // 0 inner steps, 1 leaf phases, 2 TOP passes, 3 SHADE passes
 #define MI355RT_COUNT(i, mask) do { c_exec[i] += 1; c_lanes[i] += (unsigned long long)__popcll(mask); } while (0)
 #else
@@ -974,6 +1000,12 @@ DI void render_ctr_state_machine(const RenderParams& P) {
         const uint32_t nS = (uint32_t)__popcll(__ballot(state == ST_SHADE));
         const uint32_t nI = wc.exhausted() ? 0u : (uint32_t)__popcll(__ballot(state == ST_IDLE));
         if (nT + nP + nS + nI == 0u) break;
+#ifdef MI355RT_STAMPS
+        if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths
+            if (t_dry == 0ull) { t_dry = __builtin_amdgcn_s_memrealtime(); live_at_dry = nT + nP + nS; }
+            ++drain_iters;
+        }
+#endif
 
         if (nT != 0u && (nT >= trav_min || nP + nS + nI == 0u)) {
             // ---- TRAV: one while-while round.  Inner-node steps and the leaf phase are themselves voted: step
@@ -985,21 +1017,21 @@ DI void render_ctr_state_machine(const RenderParams& P) {
 #define MI355RT_TRAV_UNROLL 4                              // box tests per vote (the vote costs a third of a step; A/B: 1 -> 4 = -5 %, 8 and 16 lose again)
 #endif
             for (int it = 0; it < MI355RT_TRAV_STEPS; it += MI355RT_TRAV_UNROLL) {
-                const bool walking = (state == ST_TRAV) && mt.leaf_b == 0u && mt.node < mt.end;
+                const bool walking = (state == ST_TRAV) && mt.leaf_b == 0u && mt.node != NODE_END;
                 const uint64_t wm = __ballot(walking);
                 const uint64_t lm = __ballot(state == ST_TRAV && mt.leaf_b != 0u);
                 if (wm == 0ull || __popcll(wm) * MI355RT_TRAV_BIAS < __popcll(lm)) break;
                 MI355RT_COUNT(0, wm);
                 if (walking) {
-                    mesh_step<FIXED_AABB>(n4, EPS, mt);
+                    mesh_step<FIXED_AABB, true>(n4, lds, lds_count, EPS, mt);
 #pragma unroll
                     for (int u = 1; u < MI355RT_TRAV_UNROLL; ++u)
-                        if (mt.leaf_b == 0u && mt.node < mt.end) mesh_step<FIXED_AABB>(n4, EPS, mt);
+                        if (mt.leaf_b == 0u && mt.node != NODE_END) mesh_step<FIXED_AABB, true>(n4, lds, lds_count, EPS, mt);
                 }
             }
             MI355RT_COUNT(1, __ballot(state == ST_TRAV && mt.leaf_b != 0u));
             if (state == ST_TRAV && mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
-            if (state == ST_TRAV && mt.leaf_b == 0u && mt.node >= mt.end) { state = ST_TOP; walk_done = true; }
+            if (state == ST_TRAV && mt.leaf_b == 0u && mt.node == NODE_END) { state = ST_TOP; walk_done = true; }
             prof.mark(0);
             continue;
         }
@@ -1024,10 +1056,10 @@ DI void render_ctr_state_machine(const RenderParams& P) {
                                 mesh_setup(pr, ps.ro, ps.rd, closest, mt);
 #pragma unroll 1
                                 for (uint32_t k = 0; k < P.inline_steps; ++k) {
-                                    if (mt.leaf_b != 0u || mt.node >= mt.end) break;
-                                    mesh_step<FIXED_AABB>(n4, EPS, mt);
+                                    if (mt.leaf_b != 0u || mt.node == NODE_END) break;
+                                    mesh_step<FIXED_AABB, true>(n4, lds, lds_count, EPS, mt);
                                 }
-                                if (mt.leaf_b == 0u && mt.node >= mt.end) walk_done = true;   // walked off the tree without meeting a leaf
+                                if (mt.leaf_b == 0u && mt.node == NODE_END) walk_done = true;   // walked off the tree without meeting a leaf
                             }
                             if (walk_done) { hit = mesh_finalize(pr, t4, mt, ps.ro, ps.rd, EPS, closest, best); walk_done = false; }
                             else { state = ST_TRAV; advance = false; }
@@ -1058,12 +1090,21 @@ DI void render_ctr_state_machine(const RenderParams& P) {
         for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
         for (int i = 0; i < 4; ++i) { atomicAdd(&P.stats[8 + 2 * i], c_exec[i]); atomicAdd(&P.stats[9 + 2 * i], c_lanes[i]); }
     }
+    if (P.wave_times) {
+        const unsigned long long t_wave1 = __builtin_amdgcn_s_memrealtime();
+        const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        const uint32_t np = wave_sum(n_paths);
+        if (lane == 0) {
+            unsigned long long* w = P.wave_times + WAVE_TIME_WORDS * (size_t)wid;
+            w[0] = t_wave0; w[1] = t_wave1; w[2] = np; w[3] = t_dry ? t_dry : t_wave1; w[4] = drain_iters; w[5] = live_at_dry;
+        }
+    }
 #endif
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
     if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }
 }
-__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm(const RenderParams P) { render_ctr_state_machine<false>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SMK k_render_ctr_sm_fixaabb(const RenderParams P) { render_ctr_state_machine<true>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_sm(const RenderParams P) { render_ctr_state_machine<false>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_sm_fixaabb(const RenderParams P) { render_ctr_state_machine<true>(P); }
 
 // ===================================================================================================
 // k_resolve -- ordered per-pixel sum, 1/spp, sqrt gamma, pack (renderer.rs:100-120), without LDS.
@@ -1154,16 +1195,61 @@ __global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
     if (P.stats) { atomicAdd(&P.stats[0], (unsigned long long)P.width * P.spp); atomicAdd(&P.stats[1], n_rays); }
 }
 
+// ===================================================================================================
+// Diagnostic kernels: one Material::scatter / one HittableList::hit per lane through the device functions above
+// (tests/test_kat_functions.py compares them with independent numpy float32 known answers).
+// ===================================================================================================
+__global__ void __launch_bounds__(64) k_debug_scatter(const DevMat* __restrict__ mats, const DebugScatterIn* __restrict__ in, DebugScatterOut* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DebugScatterIn r = in[i];
+    Hit h; h.t = 0.f; h.p = mk(r.p[0], r.p[1], r.p[2]); h.n = mk(r.n[0], r.n[1], r.n[2]);
+    h.mat_ff = r.material | (r.front_face ? 0x80000000u : 0u);
+    RngCtr rng; rng.start(r.k0, r.k1, r.x, r.s); rng.ray = r.ray; rng.load_block0();
+    const float4 q0 = reinterpret_cast<const float4*>(mats + r.material)[0];
+    f3 no = mk(0, 0, 0), nd = mk(0, 0, 0), atten = mk(0, 0, 0), emitted = mk(0, 0, 0);
+    const bool ok = surface_scatter(mats, q0, h, mk(r.rd[0], r.rd[1], r.rd[2]), rng, no, nd, atten, emitted);
+    DebugScatterOut o{};
+    o.scattered = ok ? 1.0f : 0.0f;
+    o.o[0] = no.x; o.o[1] = no.y; o.o[2] = no.z; o.d[0] = nd.x; o.d[1] = nd.y; o.d[2] = nd.z;
+    o.atten[0] = atten.x; o.atten[1] = atten.y; o.atten[2] = atten.z; o.emitted[0] = emitted.x; o.emitted[1] = emitted.y; o.emitted[2] = emitted.z;
+    out[i] = o;
+}
+__global__ void __launch_bounds__(64) k_debug_hit(const DevPrim* prims_, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris,
+                                                  const DebugHitIn* __restrict__ in, DebugHitOut* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DebugHitIn r = in[i];
+    const f3 ro = mk(r.o[0], r.o[1], r.o[2]), rd = normalized(mk(r.d[0], r.d[1], r.d[2]));       // Ray::new, ray.rs:12-17
+    Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
+    const bool hit = hit_scene<true>((cprim_t)prims_, n_prims, nodes, tris, ro, rd, h);
+    DebugHitOut o{};
+    o.hit = hit ? 1.0f : 0.0f;
+    if (hit) {
+        o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z; o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z; o.t = h.t;
+        o.material = (float)(h.mat_ff & 0x7FFFFFFFu); o.front_face = (h.mat_ff >> 31) ? 1.0f : 0.0f;
+    }
+    out[i] = o;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
+int launch_debug_scatter(const DevMat* mats, const DebugScatterIn* in, DebugScatterOut* out, uint32_t n, void* stream) {
+    hipLaunchKernelGGL(k_debug_scatter, dim3((n + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, mats, in, out, n);
+    return (int)hipGetLastError();
+}
+int launch_debug_hit(const DevPrim* prims, uint32_t n_prims, const DevNode* nodes, const DevTri* tris, const DebugHitIn* in, DebugHitOut* out, uint32_t n, void* stream) {
+    hipLaunchKernelGGL(k_debug_hit, dim3((n + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, prims, n_prims, nodes, tris, in, out, n);
+    return (int)hipGetLastError();
+}
 int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blocks, void* stream) {
     switch (variant) {
         case KERNEL_LOCKSTEP:        hipLaunchKernelGGL(k_render_ctr_nomesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_MESH:   hipLaunchKernelGGL(k_render_ctr_mesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_SIMPLE: hipLaunchKernelGGL(k_render_ctr_simple, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
-        case KERNEL_STATE_MACHINE_FIXAABB: hipLaunchKernelGGL(k_render_ctr_sm_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
-        default:                     hipLaunchKernelGGL(k_render_ctr_sm, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_STATE_MACHINE_FIXAABB: hipLaunchKernelGGL(k_render_ctr_sm_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
+        default:                     hipLaunchKernelGGL(k_render_ctr_sm, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
     }
     return (int)hipGetLastError();
 }
@@ -1183,7 +1269,7 @@ int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs,
                    : variant == KERNEL_STATE_MACHINE_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_sm_fixaabb)
                                                        : reinterpret_cast<const void*>(k_render_ctr_sm);
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK_THREADS, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)block_threads_of(variant), 0);
     if (e != hipSuccess) return (int)e;
     hipFuncAttributes fa;
     e = hipFuncGetAttributes(&fa, fn);

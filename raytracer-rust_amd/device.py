@@ -98,6 +98,46 @@ def render_multi(scene, camera, settings, devices, options=None, want_linear=Tru
     return packed, linear, stats
 
 
+def debug_scatter(materials, records, hip_device=0):
+    """Diagnostic: one Material::scatter per record on the device.  materials: ctypes array of abi.Material;
+    records: (material index, front_face, rd[3], p[3], n[3], (k0, k1, x, s, ray)).  Returns float32 [n, 10] rows
+    (scattered, origin[3], direction[3], attenuation[3]) -- the layout of the oracle's hook."""
+    sc = abi.Scene()
+    sc.materials, sc.n_materials = materials, len(materials)
+    sc.miss_color[:] = (0.5, 0.5, 0.5)
+    ctx = Context(hip_device)
+    try:
+        ctx.set_scene(sc, abi.Camera(), abi.Settings(1, 1, 1, 1))
+        n = len(records)
+        rin = np.zeros((n, 16), np.uint32)
+        for i, (mi, ff, rd, p, nn, ctr) in enumerate(records):
+            rin[i, 0], rin[i, 1] = mi, 1 if ff else 0
+            rin[i, 2:11] = np.concatenate([np.asarray(rd, np.float32), np.asarray(p, np.float32), np.asarray(nn, np.float32)]).view(np.uint32)
+            rin[i, 11:16] = ctr
+        out = np.zeros((n, 16), np.float32)
+        _check(lib().mi355rt_debug_scatter(ctx._h, C.c_void_p(rin.ctypes.data), n, C.c_void_p(out.ctypes.data)), "mi355rt_debug_scatter")
+        return out[:, :10].copy()
+    finally:
+        ctx.close()
+
+
+def debug_hit(scene, rays, hip_device=0):
+    """Diagnostic: closest hit of each (origin, unnormalised direction) against `scene` on the device.  Returns float32 [n, 10]:
+    position[3], normal[3], t, material, front_face, hit."""
+    ctx = Context(hip_device)
+    try:
+        ctx.set_scene(scene, abi.Camera(), abi.Settings(1, 1, 1, 1))
+        n = len(rays)
+        rin = np.zeros((n, 6), np.float32)
+        for i, (o, d) in enumerate(rays):
+            rin[i, :3], rin[i, 3:] = o, d
+        out = np.zeros((n, 12), np.float32)
+        _check(lib().mi355rt_debug_hit(ctx._h, C.c_void_p(rin.ctypes.data), n, C.c_void_p(out.ctypes.data)), "mi355rt_debug_hit")
+        return out[:, :10].copy()
+    finally:
+        ctx.close()
+
+
 class Context:
     """Resident-scene API: upload once, render many times into DEVICE buffers."""
 

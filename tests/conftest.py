@@ -3,6 +3,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- FIRST: torch ships its own HIP runtime; when libmi355rt.so initialises the system's copy before torch is imported, torch.cuda later reports "No HIP GPUs are available" (two runtimes in one process)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

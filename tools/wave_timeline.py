@@ -8,13 +8,17 @@ os.environ["MI355RT_WAVE_TIMES"] = "1"
 import numpy as np, torch
 torch.zeros(1, device="cuda")
 host, device, abi = pkg("host"), pkg("device"), pkg("abi")
-sc = host.LoadedScene(os.path.join(ROOT, "data/scenes/tungsten/cornell-box/scene.json"), 800, 600, 256, 30)
+SCENES = {"cornell": ("data/scenes/tungsten/cornell-box/scene.json", 30, False), "semesterbild": ("data/scenes/semesterbild.json", 30, False),
+          "teapot": ("data/scenes/tungsten/teapot/scene.json", 64, True)}
+path, depth, skip = SCENES[sys.argv[1] if len(sys.argv) > 1 else "cornell"]
+sc = host.LoadedScene(os.path.join(ROOT, path), 800, 600, 256, depth, skip_unknown_primitives=skip)
 ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings)
 out = torch.zeros(800 * 600, dtype=torch.int32, device="cuda")
 for parts in (1, 8):
     opt = abi.Options.make(strip_rows=5, n_parts=parts, part=0)
     for _ in range(3): st = ctx.render(out.data_ptr(), None, opt, None, want_stats=True)
     buf = np.zeros(6 * 8192, np.uint64); n = C.c_uint32()
+    device.lib().mi355rt_debug_read_wave_times.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32, C.POINTER(C.c_uint32)]
     assert device.lib().mi355rt_debug_read_wave_times(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 8192, C.byref(n)) == 0
     w = buf[:6 * n.value].reshape(-1, 6).astype(np.float64)
     t0 = w[:, 0].min(); start = (w[:, 0] - t0) / 100.0; end = (w[:, 1] - t0) / 100.0     # microseconds (100 MHz)
