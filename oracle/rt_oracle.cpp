@@ -42,6 +42,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <algorithm>
@@ -388,9 +389,136 @@ bool bvh_intersect_recursive(const BVHNode* node, const Ray& ray, const std::vec
 }
 
 // ------------------------------------------------------------------------------------------------
+// STUDY ONLY (tools/nearfirst_study.py): would a near-child-first walk with an explicit stack return
+// the hit the reference's fixed left-then-right recursion returns?  Same box test, same triangle test; an inner node tests
+// both child boxes, descends into the one the ray enters first and stacks the other, which is tested AGAIN with the
+// current t_max when popped.  Equal-t hits are resolved as the reference resolves them: the reference only ever replaces
+// a hit by a strictly closer one while visiting triangles in pre-order, so of several triangles at the minimal t it
+// returns the first in pre-order -- here: accept t == best only for a smaller pre-order position.
+// Never used for rendering.
+// ------------------------------------------------------------------------------------------------
+struct WalkStudy {
+    unsigned long long walks = 0, differ_tri = 0, differ_hitmiss = 0, differ_t_only = 0, nodes_ref = 0, nodes_ordered = 0,
+                       tris_ref = 0, tris_ordered = 0;
+};
+static WalkStudy* g_walk_study_total = nullptr;              // armed by oracle_walk_study(); summed over the worker threads
+static std::mutex g_walk_study_mutex;
+static thread_local WalkStudy t_walk_study;
+static thread_local WalkStudy* g_walk_study = nullptr;      // per worker thread: &t_walk_study while a study render runs
+
+static bool aabb_entry(const Aabb& b, const Ray& ray, float t_min, float t_max, float& entry) {   // Aabb::intersect + the entry distance it ends with
+    for (int axis = 0; axis < 3; ++axis) {
+        float inv_d = 1.0f / idx(ray.direction, axis);
+        float t0 = (idx(b.min, axis) - idx(ray.origin, axis)) * inv_d;
+        float t1 = (idx(b.max, axis) - idx(ray.origin, axis)) * inv_d;
+        if (inv_d < 0.0f) std::swap(t0, t1);
+        t_min = std::fmax(t_min, t0);
+        t_max = std::fmin(t_max, t1);
+        if (g_fixed_aabb ? (t_max < t_min) : (t_max <= t_min)) return false;
+    }
+    entry = t_min;
+    return true;
+}
+
+// pre-order position of every leaf's first triangle (the reference's visiting order), filled once per mesh for the study
+static void preorder_positions(const BVHNode* n, std::vector<uint32_t>& pos_of_tri, uint32_t& next) {
+    if (!n->left) { for (uint32_t id : n->triangle_indices) pos_of_tri[id] = next++; return; }
+    preorder_positions(n->left.get(), pos_of_tri, next);
+    preorder_positions(n->right.get(), pos_of_tri, next);
+}
+
+static bool bvh_intersect_ordered(const BVHNode* root, const Ray& ray, const std::vector<Tri>& tris, const std::vector<uint32_t>& pos_of_tri,
+                                  float t_min, float t_max, float& best_t, uint32_t& best_tri, WalkStudy& st) {
+    best_t = t_max; best_tri = 0xFFFFFFFFu;
+    std::vector<const BVHNode*> stack;
+    float e;
+    ++st.nodes_ordered;
+    if (!aabb_entry(root->bounds, ray, t_min, best_t, e)) return false;
+    const BVHNode* node = root;
+    for (;;) {
+        if (!node->left) {
+            for (uint32_t id : node->triangle_indices) {
+                ++st.tris_ordered;
+                const Tri& tr = tris[id];
+                V3 edge1 = tr.v1 - tr.v0, edge2 = tr.v2 - tr.v0;
+                V3 h = cross(ray.direction, edge2);
+                float a = dot(edge1, h);
+                if (std::fabs(a) < EPSILON) continue;
+                float f = 1.0f / a;
+                V3 s = ray.origin - tr.v0;
+                float u = f * dot(s, h);
+                if (!(u >= 0.0f && u <= 1.0f)) continue;
+                V3 q = cross(s, edge1);
+                float v = f * dot(ray.direction, q);
+                if (v < 0.0f || u + v > 1.0f) continue;
+                float t = f * dot(edge2, q);
+                if (!(t > t_min)) continue;
+                if (t < best_t || (t == best_t && best_tri != 0xFFFFFFFFu && pos_of_tri[id] < pos_of_tri[best_tri])) { best_t = t; best_tri = id; }
+            }
+            node = nullptr;
+        } else {
+            float el = 0, er = 0;
+            st.nodes_ordered += 2;
+            const bool hl = aabb_entry(node->left->bounds, ray, t_min, best_t, el);
+            const bool hr = aabb_entry(node->right->bounds, ray, t_min, best_t, er);
+            if (hl && hr) {
+                const bool left_first = el <= er;
+                stack.push_back(left_first ? node->right.get() : node->left.get());
+                node = left_first ? node->left.get() : node->right.get();
+            } else node = hl ? node->left.get() : hr ? node->right.get() : nullptr;
+        }
+        while (!node) {
+            if (stack.empty()) return best_tri != 0xFFFFFFFFu;
+            const BVHNode* cand = stack.back(); stack.pop_back();
+            ++st.nodes_ordered;
+            // with equal-t tie-breaking a box whose entry EQUALS best_t may still hold the pre-order-earlier triangle: the box
+            // test culls it (t_max <= t_min), exactly as the reference culls it when it comes second -- see the study's report
+            if (aabb_entry(cand->bounds, ray, t_min, best_t, e)) node = cand;
+        }
+    }
+}
+
+// reference walk that also reports the winning triangle id
+static bool bvh_intersect_reference_id(const BVHNode* node, const Ray& ray, const std::vector<Tri>& tris, float t_min, float t_max,
+                                       float& out_t, uint32_t& out_tri, WalkStudy& st) {
+    ++st.nodes_ref;
+    float e;
+    if (!aabb_entry(node->bounds, ray, t_min, t_max, e)) return false;
+    if (!node->left) {
+        bool any = false;
+        for (uint32_t id : node->triangle_indices) {
+            ++st.tris_ref;
+            const Tri& tr = tris[id];
+            V3 edge1 = tr.v1 - tr.v0, edge2 = tr.v2 - tr.v0;
+            V3 h = cross(ray.direction, edge2);
+            float a = dot(edge1, h);
+            if (std::fabs(a) < EPSILON) continue;
+            float f = 1.0f / a;
+            V3 s = ray.origin - tr.v0;
+            float u = f * dot(s, h);
+            if (!(u >= 0.0f && u <= 1.0f)) continue;
+            V3 q = cross(s, edge1);
+            float v = f * dot(ray.direction, q);
+            if (v < 0.0f || u + v > 1.0f) continue;
+            float t = f * dot(edge2, q);
+            if (t > t_min && t < t_max) { out_t = t; out_tri = id; t_max = t; any = true; }
+        }
+        return any;
+    }
+    float tl = 0, tr_ = 0; uint32_t il = 0, ir = 0;
+    const bool hl = bvh_intersect_reference_id(node->left.get(), ray, tris, t_min, t_max, tl, il, st);
+    if (hl) t_max = tl;
+    const bool hr = bvh_intersect_reference_id(node->right.get(), ray, tris, t_min, t_max, tr_, ir, st);
+    if (hl && hr) { if (tl < tr_) { out_t = tl; out_tri = il; } else { out_t = tr_; out_tri = ir; } return true; }
+    if (hl) { out_t = tl; out_tri = il; return true; }
+    if (hr) { out_t = tr_; out_tri = ir; return true; }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Scene (scene.rs + hittable.rs:29-58), built from the POD input
 // ------------------------------------------------------------------------------------------------
-struct MeshData { std::vector<Tri> tris; std::unique_ptr<BVHNode> bvh; uint32_t max_depth = 0; };
+struct MeshData { std::vector<Tri> tris; std::unique_ptr<BVHNode> bvh; uint32_t max_depth = 0; std::vector<uint32_t> pos_of_tri; /* study only */ };
 
 struct Scene {
     std::vector<float> sky; uint32_t sky_w = 0, sky_h = 0;      // scene.rs:9 skybox_hdr_image
@@ -423,6 +551,7 @@ bool build_scene(const mi355rt_scene* in, Scene& sc) {
         std::vector<uint32_t> indices(md.triangle_count);
         for (uint32_t i = 0; i < md.triangle_count; ++i) indices[i] = i;       // mesh_object.rs:44-45
         out.bvh = bvh_new(out.tris, indices.data(), indices.size(), 0, &out.max_depth);
+        if (g_walk_study_total) { out.pos_of_tri.assign(md.triangle_count, 0u); uint32_t next = 0; preorder_positions(out.bvh.get(), out.pos_of_tri, next); }
     }
     for (const auto& p : sc.prims) {
         if (p.kind >= MI355RT_PRIM_KIND_COUNT) return false;
@@ -553,6 +682,16 @@ bool mesh_hit(const mi355rt_primitive& p, const MeshData& mesh, const Ray& ray_w
     const uint64_t nodes_before = c.bvh_nodes;
     const bool walk_hit = bvh_intersect_recursive(mesh.bvh.get(), ray_obj, mesh.tris, t_min_world, t_max_world, rec, c);
     if (g_walk_hist) __atomic_fetch_add(&g_walk_hist[std::min<uint64_t>(c.bvh_nodes - nodes_before, WALK_HIST_BINS - 1)], 1ull, __ATOMIC_RELAXED);
+    if (g_walk_study && !mesh.pos_of_tri.empty()) {      // study: the same walk in both orders (single-threaded runs only)
+        WalkStudy& st = *g_walk_study;
+        float t_ref = 0, t_ord = 0; uint32_t i_ref = 0xFFFFFFFFu, i_ord = 0xFFFFFFFFu;
+        const bool h_ref = bvh_intersect_reference_id(mesh.bvh.get(), ray_obj, mesh.tris, t_min_world, t_max_world, t_ref, i_ref, st);
+        const bool h_ord = bvh_intersect_ordered(mesh.bvh.get(), ray_obj, mesh.tris, mesh.pos_of_tri, t_min_world, t_max_world, t_ord, i_ord, st);
+        ++st.walks;
+        if (h_ref != h_ord) ++st.differ_hitmiss;
+        else if (h_ref && i_ref != i_ord) ++st.differ_tri;
+        else if (h_ref && std::memcmp(&t_ref, &t_ord, 4) != 0) ++st.differ_t_only;
+    }
     if (!walk_hit) return false;
     float pw[4], nw[4];
     mat_mul_vec4(o2w, rec.position.x, rec.position.y, rec.position.z, 1.0f, pw);
@@ -872,6 +1011,9 @@ struct oracle_counters {
 // CTR -> forward throughput), 0 = tail, 1 = forward.
 // Arm (hist != NULL, WALK_HIST_BINS entries, caller-owned) or disarm (NULL) the walk-length histogram.
 void oracle_walk_histogram(unsigned long long* hist) { g_walk_hist = hist; }
+// Study hook (tools/nearfirst_study.py): while `out8` is non-null every mesh walk of oracle_render is ALSO run in near-first
+// order and compared; out8 = walks, differ_tri, differ_hitmiss, differ_t_only, nodes_ref, nodes_ordered, tris_ref, tris_ordered.
+void oracle_walk_study(unsigned long long* out8) { g_walk_study_total = reinterpret_cast<WalkStudy*>(out8); }
 int oracle_render(const mi355rt_scene* scene_in, const mi355rt_camera* cam, const mi355rt_settings* st,
                   const mi355rt_options* opt, int n_threads, int fold, uint32_t* out_packed, float* out_linear,
                   oracle_counters* counters_out) {
@@ -894,6 +1036,7 @@ int oracle_render(const mi355rt_scene* scene_in, const mi355rt_camera* cam, cons
     auto t_begin = std::chrono::steady_clock::now();
     auto worker = [&](int tid) {
         Counters c;
+        if (g_walk_study_total) { t_walk_study = WalkStudy(); g_walk_study = &t_walk_study; }
         for (;;) {
             size_t j = next_row.fetch_add(1);
             if (j >= sel.rows.size()) break;
@@ -929,6 +1072,13 @@ int oracle_render(const mi355rt_scene* scene_in, const mi355rt_camera* cam, cons
             if (rng_mode == MI355RT_RNG_REF) c.rng_words += chacha.words_drawn;
         }
         per_thread[(size_t)tid] = c;
+        if (g_walk_study) {
+            std::lock_guard<std::mutex> lock(g_walk_study_mutex);
+            WalkStudy& T = *g_walk_study_total; const WalkStudy& w = t_walk_study;
+            T.walks += w.walks; T.differ_tri += w.differ_tri; T.differ_hitmiss += w.differ_hitmiss; T.differ_t_only += w.differ_t_only;
+            T.nodes_ref += w.nodes_ref; T.nodes_ordered += w.nodes_ordered; T.tris_ref += w.tris_ref; T.tris_ordered += w.tris_ordered;
+            g_walk_study = nullptr;
+        }
     };
     std::vector<std::thread> pool;
     for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "../../../include/mi355rt.h"
@@ -87,7 +89,9 @@ extern "C" int mi355rt_bvh_build(const mi355rt_triangle* triangles, uint32_t n_t
     using namespace mi355rt_host;
     if (!inout_n_nodes || !inout_n_indices) return set_error(MI355RT_ERR_INVALID, "bvh_build: count pointers are null");
     std::vector<mi355rt_bvh_node> nodes; std::vector<uint32_t> indices; uint32_t md = 0;
-    int rc = bvh_build(triangles, n_triangles, nodes, indices, md);
+    int rc;
+    try { rc = bvh_build(triangles, n_triangles, nodes, indices, md); }
+    catch (const std::exception& e) { return set_error(MI355RT_ERR_OOM, std::string("bvh_build: ") + e.what()); }   // nothing is thrown across the C ABI
     if (rc) return rc;
     if (out_nodes || out_indices) {
         if (!out_nodes || !out_indices || *inout_n_nodes < nodes.size() || *inout_n_indices < indices.size())

@@ -3,6 +3,7 @@
 // restated for what that call yields: header lines up to a blank line, "-Y H +X W", scanlines either flat
 // RGBE or new-style run-length encoded (marker 2 2 hi lo, four channel planes), and the RGBE -> f32
 // conversion  c * 2^(e - 136)  (zero when e == 0).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -27,6 +28,11 @@ int load_radiance_hdr(const std::string& path, uint32_t& width, uint32_t& height
     line(ln);
     int H = 0, W = 0;
     if (std::sscanf(ln.c_str(), "-Y %d +X %d", &H, &W) != 2 || H <= 0 || W <= 0) return set_error(MI355RT_ERR_IO, "unsupported HDR orientation: " + ln);
+    // Refuse before allocating: the device caps a skybox at 2^28 texels, and a file cannot hold more scanlines than its
+    // bytes allow (flat: 4 W bytes per line; run-length: at least the 4-byte marker + 2 bytes per 127-pixel run and channel).
+    if ((uint64_t)W * (uint64_t)H > (1ull << 28)) return set_error(MI355RT_ERR_IO, "HDR larger than 2^28 pixels: " + ln);
+    const uint64_t min_line = std::min<uint64_t>((uint64_t)W * 4u, 4u + 8u * (((uint64_t)W + 126u) / 127u));
+    if ((uint64_t)H * min_line > b.size() - std::min(p, b.size())) return set_error(MI355RT_ERR_IO, "HDR truncated");
     width = (uint32_t)W; height = (uint32_t)H;
     rgb.assign((size_t)W * H * 3, 0.0f);
     std::vector<unsigned char> scan((size_t)W * 4);
