@@ -190,9 +190,22 @@ struct RngRef {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// Intersection.  Hit record (hittable.rs:10-27) kept in registers; `mat_ff` = material | front_face<<31.
+// Intersection.  The list walk (hittable.rs:45-58) only needs to know WHICH primitive is closest so far and at what t; the
+// HitRecord (hittable.rs:10-27) of all but the last winner is never looked at.  So the walk carries a 4-register candidate
+// (Cand) instead of the 8-register record, and finish_hit() builds the record of the winner once per ray, with exactly the
+// arithmetic the reference's hit() performs for it (same inputs, same operations, same order -> same bits).  Measured
+// reason: the compiler keeps a loop-carried record in two register sets and copies it at every nesting level of every
+// primitive test -- 24-33 v_mov per quad, a third of its instructions; the copies scale with the size of the state.
 // ---------------------------------------------------------------------------------------------------
-struct Hit { float t; f3 p; f3 n; uint32_t mat_ff; };
+struct Hit { float t; f3 p; f3 n; uint32_t mat_ff; };            // the finished record; `mat_ff` = material | front_face << 31
+constexpr uint32_t CAND_NONE = 0xFFFFFFFFu;
+struct Cand {
+    float t;            // closest hit distance so far (world), +inf while idx == CAND_NONE
+    uint32_t idx;       // list index of the primitive that owns it
+    float aux;          // cube: the object-space slab distance t_hit (cube.rs:98); mesh: the walk's object-space best_t
+    uint32_t aux2;      // mesh: the winning triangle (index into the leaf-ordered array)
+};
+DI void cand_reset(Cand& c) { c.t = __builtin_inff(); c.idx = CAND_NONE; c.aux = 0.f; c.aux2 = 0u; }
 
 DI void set_face(Hit& h, f3 rd, f3 outward, uint32_t material) {                 // hittable.rs:19-26
     bool front = dot(rd, outward) < 0.0f;
@@ -201,43 +214,40 @@ DI void set_face(Hit& h, f3 rd, f3 outward, uint32_t material) {                
 }
 
 // objects/sphere.rs:15-53 (rejections folded into one predicate; sqrt of a negative discriminant is discarded)
-DI bool hit_sphere(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
+DI bool hit_sphere(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     f3 center = mk(pr->d[0], pr->d[1], pr->d[2]); float radius = pr->d[3];
     f3 oc = ro - center;
     float a = dot(rd, rd);
     float half_b = dot(oc, rd);
-    float c = dot(oc, oc) - radius * radius;
-    float disc = half_b * half_b - a * c;
+    float cc = dot(oc, oc) - radius * radius;
+    float disc = half_b * half_b - a * cc;
     float sqrtd = sqrtf(disc);
     float r0 = (-half_b - sqrtd) / a, r1 = (-half_b + sqrtd) / a;
+    const float t_max = c.t;
     const bool ok0 = !(r0 <= t_min || r0 >= t_max), ok1 = !(r1 <= t_min || r1 >= t_max);
     if (disc < 0.0f || !(ok0 || ok1)) return false;
-    const float root = ok0 ? r0 : r1;
-    h.t = root;
-    h.p = ro + rd * root;
-    set_face(h, rd, divf(h.p - center, radius), pr->material);
+    c.t = ok0 ? r0 : r1; c.idx = i;
     return true;
 }
 
 // objects/plane.rs:26-56
-DI bool hit_plane(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
+DI bool hit_plane(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     f3 p1 = mk(pr->d[0], pr->d[1], pr->d[2]), n = mk(pr->d[3], pr->d[4], pr->d[5]);
     float denom = dot(n, rd);
     float t = dot(n, p1 - ro) / denom;
-    if ((fabsf(denom) < EPS) || (t <= t_min || t >= t_max)) return false;
-    h.t = t; h.p = ro + rd * t;
-    set_face(h, rd, n, pr->material);
+    if ((fabsf(denom) < EPS) || (t <= t_min || t >= c.t)) return false;
+    c.t = t; c.idx = i;
     return true;
 }
 
 // tungsten/objects/quad.rs:83-132.  The two cheap rejections (parallel ray, t out of range) are folded into one
 // predicate so the wave takes a single branch into the parallelogram test; the arithmetic is unchanged (the
 // division also runs for |denom| < EPS lanes, whose result is discarded).
-DI bool hit_quad(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
+DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     f3 n = mk(pr->d[9], pr->d[10], pr->d[11]);
     float denom = dot(n, rd);
     float t = (pr->d[12] - dot(n, ro)) / denom;
-    const bool candidate = !(fabsf(denom) < EPS) && !(t <= t_min || t >= t_max);
+    const bool candidate = !(fabsf(denom) < EPS) && !(t <= t_min || t >= c.t);
     if (!candidate) return false;
     f3 hit_pos = ro + rd * t;
     f3 v = hit_pos - mk(pr->d[0], pr->d[1], pr->d[2]);
@@ -245,48 +255,43 @@ DI bool hit_quad(cprim_t pr, f3 ro, f3 rd, float t_min, float t_max, Hit& h) {
     float l1 = dot(v, mk(pr->d[6], pr->d[7], pr->d[8])) * pr->d[14];
     const float lo = -EPS, hi = 1.0f + EPS;
     if (!((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi))) return false;
-    h.t = t; h.p = hit_pos;
-    const bool front = denom < 0.0f;                      // dot(ray.direction, normal) is the same sum of the same products
-    h.n = front ? n : -n;
-    h.mat_ff = pr->material | (front ? 0x80000000u : 0u);
+    c.t = t; c.idx = i;
     return true;
 }
 
-// glam Mat4 * Vec4 pieces on the DevPrim cube/mesh record (see rt_device.h for the layout)
-DI f3 xform_w2o_point(cprim_t pr, f3 p) {            // (w2o * (p, 1)).xyz
+// glam Mat4 * Vec4 pieces on the DevPrim cube/mesh record (see rt_device.h for the layout).  PrimPtr is the wave-uniform
+// constant-address-space pointer of the list walk (scalar loads) or a per-lane global pointer in finish_hit().
+template <class PrimPtr> DI f3 xform_w2o_point(PrimPtr pr, f3 p) {            // (w2o * (p, 1)).xyz
     const auto* m = pr->d;
     return mk(((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12], ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13],
               ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14]);
 }
-DI f3 xform_w2o_dir(cprim_t pr, f3 v) {              // (w2o * (v, 0)).xyz ; zd = w_axis * 0.0f keeps -0.0 behaviour
+template <class PrimPtr> DI f3 xform_w2o_dir(PrimPtr pr, f3 v) {              // (w2o * (v, 0)).xyz ; zd = w_axis * 0.0f keeps -0.0 behaviour
     const auto* m = pr->d;
     return mk(((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[28], ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[29],
               ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[30]);
 }
-DI f3 xform_o2w_point(cprim_t pr, f3 p) {            // (o2w * (p, 1)).xyz
+template <class PrimPtr> DI f3 xform_o2w_point(PrimPtr pr, f3 p) {            // (o2w * (p, 1)).xyz
     const auto* m = pr->d + 16;
     return mk(((m[0] * p.x + m[3] * p.y) + m[6] * p.z) + m[9], ((m[1] * p.x + m[4] * p.y) + m[7] * p.z) + m[10],
               ((m[2] * p.x + m[5] * p.y) + m[8] * p.z) + m[11]);
 }
-DI f3 xform_normal(cprim_t pr, f3 n) {               // (w2o.transpose() * (n, 0)).xyz
+template <class PrimPtr> DI f3 xform_normal(PrimPtr pr, f3 n) {               // (w2o.transpose() * (n, 0)).xyz
     const auto* m = pr->d;
     return mk(((m[0] * n.x + m[1] * n.y) + m[2] * n.z) + m[31], ((m[4] * n.x + m[5] * n.y) + m[6] * n.z) + m[32],
               ((m[8] * n.x + m[9] * n.y) + m[10] * n.z) + m[33]);
 }
 DI float glam_signum(float v) { if (v != v) return v; return copysignf(1.0f, v); }
 
-// objects/cube.rs:59-158.  The face normal (cube.rs:105-143) is DEFERRED: the list walk only needs t and the position
-// to go on, and of all the cube hits a ray collects only the closest one is ever shaded.  A hit therefore leaves the
-// object-space point in h.n and HIT_PENDING_CUBE | list index in h.mat_ff; finish_cube_hit() turns that into the
-// normal / face / material once per ray, after the list (hit_scene) or when the lane reaches SHADE (state machine).
-constexpr uint32_t HIT_PENDING_CUBE = 0x40000000u;
+// objects/cube.rs:59-158, the part that decides whether and where the cube is hit; the face normal (cube.rs:105-143) is
+// computed by finish_hit() for the winner only.
 DI uint32_t cube_axis(f3 po) {                                                          // cube.rs:112-133 as selects
     const float ax = fabsf(po.x), ay = fabsf(po.y), az = fabsf(po.z);
     const float tol = 1e-4f;
     return (fabsf(ax - 0.5f) < tol) ? 0u : (fabsf(ay - 0.5f) < tol) ? 1u : (fabsf(az - 0.5f) < tol) ? 2u
          : (ax > ay && ax > az) ? 0u : (ay > az) ? 1u : 2u;
 }
-DI bool hit_cube(cprim_t pr, uint32_t list_index, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h) {
+DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, Cand& c) {
     f3 ro = xform_w2o_point(pr, ro_w);
     f3 rd = xform_w2o_dir(pr, rd_w);
     float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
@@ -296,46 +301,35 @@ DI bool hit_cube(cprim_t pr, uint32_t list_index, f3 ro_w, f3 rd_w, float t_min,
     float t_enter = fmaxf(fminf(t1x, t2x), fmaxf(fminf(t1y, t2y), fminf(t1z, t2z)));
     float t_exit = fminf(fmaxf(t1x, t2x), fminf(fmaxf(t1y, t2y), fmaxf(t1z, t2z)));
     const float t_hit = (t_enter > 0.0f) ? t_enter : t_exit;
+    const float t_max = c.t;
     const bool candidate = !(t_exit < t_enter || t_exit <= 0.0f) && !(t_hit >= t_max || t_hit <= t_min || t_hit < EPS);   // cube.rs:90-103, one branch
     if (!candidate) return false;
     f3 po = ro + rd * t_hit;
     f3 pw = xform_o2w_point(pr, po);
     const float t_world = dot(pw - ro_w, rd_w);                                             // cube.rs:145-153: the same dot product twice
     if ((t_world < 0.0f) || (t_world < t_min || t_world > t_max)) return false;
-    h.t = t_world; h.p = pw;
-    if (has_nan(po)) {
-        // a NaN coordinate can make signum NaN -> normalize_or_zero -> the zero vector (cube.rs:134): settle it here
-        const uint32_t axis = cube_axis(po);
-        const float c = (axis == 0u) ? po.x : ((axis == 1u) ? po.y : po.z);
-        f3 nw;
-        if (c != c) nw = normalized(xform_normal(pr, mk(0.f, 0.f, 0.f)));
-        else {
-            const uint32_t code = 2u * axis + (__float_as_uint(c) >> 31);
-            const auto* t = pr->d + 34;
-            nw.x = code == 0u ? t[0] : code == 1u ? t[3] : code == 2u ? t[6] : code == 3u ? t[9] : code == 4u ? t[12] : t[15];
-            nw.y = code == 0u ? t[1] : code == 1u ? t[4] : code == 2u ? t[7] : code == 3u ? t[10] : code == 4u ? t[13] : t[16];
-            nw.z = code == 0u ? t[2] : code == 1u ? t[5] : code == 2u ? t[8] : code == 3u ? t[11] : code == 4u ? t[14] : t[17];
-        }
-        set_face(h, rd_w, nw, pr->material);
-    } else {
-        h.n = po; h.mat_ff = HIT_PENDING_CUBE | list_index;
-    }
+    c.t = t_world; c.idx = i; c.aux = t_hit;
     return true;
 }
-// The deferred half of a cube hit.  The object-space normal is +-e_axis, normalize_or_zero() of such a vector is the vector
+// The record of a cube hit.  The object-space normal is +-e_axis, normalize_or_zero() of such a vector is the vector
 // itself (1/sqrt(1) == 1), and the world normal normalized(w2o^T * (n, 0)) therefore takes one of 6 values per cube, which
-// the host precomputed with the same f32 operations (DevPrim.d[34..51], rt_api.cpp cube_normal_table).  Per-lane record:
-// lanes of one wave may have hit different cubes.
-DI void finish_cube_hit(const DevPrim* __restrict__ prims, Hit& h, f3 rd_w) {
-    const DevPrim* __restrict__ pr = prims + (h.mat_ff & (HIT_PENDING_CUBE - 1u));
-    const f3 po = h.n;
+// the host precomputed with the same f32 operations (DevPrim.d[34..51], rt_api.cpp cube_normal_table).
+template <class PrimPtr>
+DI void finish_cube(PrimPtr pr, const Cand& c, f3 ro_w, f3 rd_w, Hit& h) {
+    const f3 ro = xform_w2o_point(pr, ro_w), rd = xform_w2o_dir(pr, rd_w);
+    const f3 po = ro + rd * c.aux;                                                          // cube.rs:104
+    h.t = c.t; h.p = xform_o2w_point(pr, po);
     const uint32_t axis = cube_axis(po);
-    const float c = (axis == 0u) ? po.x : ((axis == 1u) ? po.y : po.z);
-    const uint32_t code = 2u * axis + (__float_as_uint(c) >> 31);                       // glam signum: the sign bit decides, also for +-0
-    const float* __restrict__ t = pr->d + 34u + 3u * code;
-    set_face(h, rd_w, mk(t[0], t[1], t[2]), pr->material);
+    const float cc = (axis == 0u) ? po.x : ((axis == 1u) ? po.y : po.z);
+    f3 nw;
+    if (cc != cc) nw = normalized(xform_normal(pr, mk(0.f, 0.f, 0.f)));                     // NaN signum -> normalize_or_zero -> the zero vector (cube.rs:134)
+    else {
+        const uint32_t code = 2u * axis + (__float_as_uint(cc) >> 31);                      // glam signum: the sign bit decides, also for +-0
+        const auto* t = pr->d + 34u + 3u * code;
+        nw = mk(t[0], t[1], t[2]);
+    }
+    set_face(h, rd_w, nw, pr->material);
 }
-DI bool hit_pending(const Hit& h) { return (h.mat_ff & 0xC0000000u) == HIT_PENDING_CUBE; }   // bit 31 is front_face of a finished record
 
 // mesh/mesh_object.rs:263-329 + acceleration/bvh.rs:78-170 + acceleration/aabb.rs:27-45.
 // Stackless walk over two-link nodes (rt_device.h): hit inner -> left child, everything else -> the escape link, which
@@ -350,7 +344,7 @@ struct MeshTrav {
     float best_t; uint32_t best_tri;
     uint32_t leaf_a, leaf_b;   // pending leaf (first triangle, count); leaf_b == 0: none
 };
-DI void mesh_setup(cprim_t pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {
+DI void mesh_setup(cprim_t pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {   // mesh_object.rs:264-291
     m.ro = xform_w2o_point(pr, ro_w);
     f3 rd_raw = xform_w2o_dir(pr, rd_w);
     m.len_raw = len(rd_raw);
@@ -420,54 +414,84 @@ DI void mesh_leaf(const float4* __restrict__ t4, float t_min, MeshTrav& m) {
     }
     m.leaf_b = 0;
 }
-DI bool mesh_finalize(cprim_t pr, const float4* __restrict__ t4, const MeshTrav& m, f3 ro_w, f3 rd_w, float t_min, float t_max, Hit& h) {
+// The end of Mesh::hit that decides acceptance (mesh_object.rs:312-318); the record is built by finish_mesh() for the winner.
+DI bool mesh_accept(uint32_t i, const MeshTrav& m, f3 rd_w, float t_min, Cand& c) {
     if (m.best_tri == 0xFFFFFFFFu) return false;
-    const float4 r2 = t4[3 * (size_t)m.best_tri + 2];
-    f3 tn = mk(r2.y, r2.z, r2.w);
-    f3 pos_obj = m.ro + m.rd * m.best_t;
-    f3 n_obj = (dot(m.rd, tn) < 0.0f) ? tn : -tn;                       // bvh.rs:118-124
-    f3 pw = xform_o2w_point(pr, pos_obj);
-    f3 nw = normalized(xform_normal(pr, n_obj));
     float t_world = m.best_t * m.len_raw / len(rd_w);                   // (sic) mesh_object.rs:312-314
-    if (t_world < t_min || t_world > t_max) return false;
-    h.t = t_world; h.p = pw;
-    set_face(h, rd_w, nw, pr->material);
+    if (t_world < t_min || t_world > c.t) return false;
+    c.t = t_world; c.idx = i; c.aux = m.best_t; c.aux2 = m.best_tri;
     return true;
 }
-DI bool hit_mesh(cprim_t pr, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro_w, f3 rd_w,
-                 float t_min, float t_max, Hit& h) {
+// mesh_object.rs:264-310 for the winning triangle: the object-space ray is recomputed exactly as mesh_setup() computed it.
+template <class PrimPtr>
+DI void finish_mesh(PrimPtr pr, const float4* __restrict__ t4, const Cand& c, f3 ro_w, f3 rd_w, Hit& h) {
+    const f3 ro = xform_w2o_point(pr, ro_w);
+    const f3 rd = normalized(normalized(xform_w2o_dir(pr, rd_w)));
+    const float4 r2 = t4[3 * (size_t)c.aux2 + 2];
+    f3 tn = mk(r2.y, r2.z, r2.w);
+    f3 pos_obj = ro + rd * c.aux;
+    f3 n_obj = (dot(rd, tn) < 0.0f) ? tn : -tn;                         // bvh.rs:118-124
+    h.t = c.t; h.p = xform_o2w_point(pr, pos_obj);
+    set_face(h, rd_w, normalized(xform_normal(pr, n_obj)), pr->material);
+}
+DI bool hit_mesh(cprim_t pr, uint32_t i, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro_w, f3 rd_w,
+                 float t_min, Cand& c) {
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(nodes);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(tris);
-    MeshTrav m; mesh_setup(pr, ro_w, rd_w, t_max, m);
+    MeshTrav m; mesh_setup(pr, ro_w, rd_w, c.t, m);
     while (m.node != NODE_END) {
         mesh_step(n4, nullptr, 0u, t_min, m);
         if (m.leaf_b) mesh_leaf(t4, t_min, m);
     }
-    return mesh_finalize(pr, t4, m, ro_w, rd_w, t_min, t_max, h);
+    return mesh_accept(i, m, rd_w, t_min, c);
+}
+
+// The HitRecord of the list's winner (hittable.rs:10-27), once per ray.  Lanes of a wave may have different winners, so
+// the primitive record is read per lane here (global loads; L1/L2 resident).
+template <bool HAS_MESH>
+DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__ tris, const Cand& c, f3 ro, f3 rd, Hit& h) {
+    const DevPrim* __restrict__ pr = prims + c.idx;
+    const uint32_t kind = pr->kind;
+    if (kind == MI355RT_PRIM_QUAD) {                                      // quad.rs:103-131
+        const f3 n = mk(pr->d[9], pr->d[10], pr->d[11]);
+        h.t = c.t; h.p = ro + rd * c.t;
+        set_face(h, rd, n, pr->material);                                 // dot(ray.direction, normal): the same sum of the same products as `denom`
+    } else if (kind == MI355RT_PRIM_CUBE) {
+        finish_cube(pr, c, ro, rd, h);
+    } else if (kind == MI355RT_PRIM_SPHERE) {                             // sphere.rs:35-52
+        const f3 center = mk(pr->d[0], pr->d[1], pr->d[2]); const float radius = pr->d[3];
+        h.t = c.t; h.p = ro + rd * c.t;
+        set_face(h, rd, divf(h.p - center, radius), pr->material);
+    } else if (kind == MI355RT_PRIM_PLANE) {                              // plane.rs:40-55
+        h.t = c.t; h.p = ro + rd * c.t;
+        set_face(h, rd, mk(pr->d[3], pr->d[4], pr->d[5]), pr->material);
+    } else if (HAS_MESH) {
+        finish_mesh(pr, reinterpret_cast<const float4*>(tris), c, ro, rd, h);
+    }
 }
 
 // hittable.rs:45-58 -- HittableList::hit with t_min = EPSILON, t_max = INFINITY (renderer.rs:24)
 template <bool HAS_MESH>
-DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris,
-                  f3 ro, f3 rd, Hit& best) {
-    float closest = __builtin_inff();
-    bool any = false;
+DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro, f3 rd, Cand& c) {
     for (uint32_t i = 0; i < n_prims; ++i) {
         cprim_t pr = prims + i;
-        bool hit = false;
-        // every routine writes its record only after its last rejection, so `best` itself is the output: no temporary
-        // record and no copy per accepted hit (the copies showed up as 8 v_mov per nesting level in the ISA)
         switch (pr->kind) {                               // wave-uniform: scalar branch
-            case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ro, rd, EPS, closest, best); break;
-            case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ro, rd, EPS, closest, best); break;
-            case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ro, rd, EPS, closest, best); break;
-            case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, i, ro, rd, EPS, closest, best); break;
-            default:                  if (HAS_MESH) hit = hit_mesh(pr, nodes, tris, ro, rd, EPS, closest, best); break;
+            case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ro, rd, EPS, c); break;
+            case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ro, rd, EPS, c); break;
+            case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ro, rd, EPS, c); break;
+            case MI355RT_PRIM_CUBE:   hit_cube(pr, i, ro, rd, EPS, c); break;
+            default:                  if (HAS_MESH) hit_mesh(pr, i, nodes, tris, ro, rd, EPS, c); break;
         }
-        if (hit) { closest = best.t; any = true; }
     }
-    if (any && hit_pending(best)) finish_cube_hit((const DevPrim*)prims, best, rd);
-    return any;
+}
+template <bool HAS_MESH>
+DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris,
+                  f3 ro, f3 rd, Hit& best) {
+    Cand c; cand_reset(c);
+    walk_list<HAS_MESH>(prims, n_prims, nodes, tris, ro, rd, c);
+    if (c.idx == CAND_NONE) return false;
+    finish_hit<HAS_MESH>((const DevPrim*)prims, tris, c, ro, rd, best);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -978,8 +1002,7 @@ DI void render_ctr_state_machine(const RenderParams& P) {
     ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
     uint32_t state = ST_IDLE, cursor = 0;
     bool walk_done = false;
-    float closest = __builtin_inff(); bool any_hit = false;
-    Hit best; best.t = 0.f; best.p = mk(0, 0, 0); best.n = mk(0, 0, 0); best.mat_ff = 0;
+    Cand best; cand_reset(best);                                       // the list's running winner (4 registers; the record is built at SHADE)
     MeshTrav mt; mt.ro = mk(0, 0, 0); mt.rd = mk(0, 0, 1); mt.ix = mt.iy = mt.iz = 0.f; mt.len_raw = 0.f; mt.node = NODE_END; mt.best_t = 0.f;
     mt.best_tri = 0xFFFFFFFFu; mt.leaf_a = mt.leaf_b = 0;
     uint32_t n_paths = 0, n_rays = 0;
@@ -1045,17 +1068,17 @@ DI void render_ctr_state_machine(const RenderParams& P) {
                 if (__ballot(mine) == 0ull) continue;
                 cprim_t pr = prims + i;
                 if (mine) {
-                    bool hit = false; bool advance = true;
-                    switch (pr->kind) {                                       // wave-uniform: scalar branch; `best` is written in place (see hit_scene)
-                        case MI355RT_PRIM_SPHERE: hit = hit_sphere(pr, ps.ro, ps.rd, EPS, closest, best); break;
-                        case MI355RT_PRIM_PLANE:  hit = hit_plane(pr, ps.ro, ps.rd, EPS, closest, best); break;
-                        case MI355RT_PRIM_QUAD:   hit = hit_quad(pr, ps.ro, ps.rd, EPS, closest, best); break;
-                        case MI355RT_PRIM_CUBE:   hit = hit_cube(pr, i, ps.ro, ps.rd, EPS, closest, best); break;
+                    bool advance = true;
+                    switch (pr->kind) {                                       // wave-uniform: scalar branch
+                        case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ps.ro, ps.rd, EPS, best); break;
+                        case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ps.ro, ps.rd, EPS, best); break;
+                        case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ps.ro, ps.rd, EPS, best); break;
+                        case MI355RT_PRIM_CUBE:   hit_cube(pr, i, ps.ro, ps.rd, EPS, best); break;
                         default:
                             if (!walk_done) {
                                 // Most rays leave a mesh within a few box tests (they miss its root or upper boxes):
                                 // take those steps right here so that only long walks pay a TRAV / TOP round trip.
-                                mesh_setup(pr, ps.ro, ps.rd, closest, mt);
+                                mesh_setup(pr, ps.ro, ps.rd, best.t, mt);
 #pragma unroll 1
                                 for (uint32_t k = 0; k < P.inline_steps; ++k) {
                                     if (mt.leaf_b != 0u || mt.node == NODE_END) break;
@@ -1063,11 +1086,10 @@ DI void render_ctr_state_machine(const RenderParams& P) {
                                 }
                                 if (mt.leaf_b == 0u && mt.node == NODE_END) walk_done = true;   // walked off the tree without meeting a leaf
                             }
-                            if (walk_done) { hit = mesh_finalize(pr, t4, mt, ps.ro, ps.rd, EPS, closest, best); walk_done = false; }
+                            if (walk_done) { mesh_accept(i, mt, ps.rd, EPS, best); walk_done = false; }
                             else { state = ST_TRAV; advance = false; }
                             break;
                     }
-                    if (hit) { closest = best.t; any_hit = true; }
                     if (advance) ++cursor;
                 }
             }
@@ -1077,12 +1099,14 @@ DI void render_ctr_state_machine(const RenderParams& P) {
         }
         // ---- SHADE + regeneration (lanes in TOP / TRAV are left untouched) ----
         bool live = (state == ST_SHADE);
-        if (live && any_hit && hit_pending(best)) finish_cube_hit(P.prims, best, ps.rd);   // the deferred cube normal, once per ray
+        const bool any_hit = live && best.idx != CAND_NONE;
+        Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
+        if (any_hit) finish_hit<true>(P.prims, P.tris, best, ps.ro, ps.rd, h);             // the winner's HitRecord, once per ray
         const bool part = live || state == ST_IDLE;
         MI355RT_COUNT(3, __ballot(part));
-        shade_and_regenerate<false>(P, wc, lane, live, part, any_hit, best, ps, n_paths, n_rays, prof);
+        shade_and_regenerate<false>(P, wc, lane, live, part, any_hit, h, ps, n_paths, n_rays, prof);
         if (part) {
-            if (live) { state = ST_TOP; cursor = 0; closest = __builtin_inff(); any_hit = false; walk_done = false; }
+            if (live) { state = ST_TOP; cursor = 0; cand_reset(best); walk_done = false; }
             else state = ST_IDLE;
         }
         prof.mark(4);

@@ -1,0 +1,63 @@
+"""Robustness of the resident-scene API on a real GPU (ADVICE rt_api.cpp:347):
+  * a radiance workspace that does not fit is not an error: the band is halved until hipMalloc succeeds, and the banded image
+    is bit-identical to the one-band image;
+  * one context driven from two HIP streams: the second render waits for the first (the workspaces belong to one render at a
+    time), so both images are exactly what each call gives on its own.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SCENES
+
+pytestmark = pytest.mark.gpu
+
+
+def test_out_of_memory_for_the_workspace_falls_back_to_smaller_bands(native, abi):
+    host, device = native
+    W, H, spp = 800, 600, 1024                                       # 491.5 M samples -> a 7.9 GB one-band workspace
+    sc = host.LoadedScene(SCENES["cornell"], W, H, spp, 8)
+    n = W * H
+    ref = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx = device.Context(0)
+    ctx.set_scene(sc, sc.camera, sc.settings)
+    st0 = ctx.render(ref.data_ptr(), None, abi.Options.make(), None, want_stats=True)
+    ctx.close()
+    assert st0.bands == 1
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    hog = torch.empty(max(free - (3 << 30), 0), dtype=torch.uint8, device="cuda")      # leave about 3 GB
+    try:
+        out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ctx = device.Context(0)
+        ctx.set_scene(sc, sc.camera, sc.settings)
+        st = ctx.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
+        ctx.close()
+        assert st.bands >= 4 and st.samples == st0.samples and st.rays == st0.rays
+        assert torch.equal(out, ref)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+
+
+def test_one_context_on_two_streams_is_serialised(native, abi):
+    host, device = native
+    sc = host.LoadedScene(SCENES["cornell"], 400, 300, 64, 8)
+    n = 400 * 300
+    a_opt, b_opt = abi.Options.make(strip_rows=3, n_parts=2, part=0), abi.Options.make(strip_rows=3, n_parts=2, part=1)
+    ctx = device.Context(0)
+    ctx.set_scene(sc, sc.camera, sc.settings)
+    want_a = torch.zeros(n // 2, dtype=torch.int32, device="cuda"); want_b = torch.zeros(n // 2, dtype=torch.int32, device="cuda")
+    ctx.render(want_a.data_ptr(), None, a_opt, None); torch.cuda.synchronize()
+    ctx.render(want_b.data_ptr(), None, b_opt, None); torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(4):                                               # back to back on alternating streams, no host sync in between
+        got_a = torch.zeros(n // 2, dtype=torch.int32, device="cuda"); got_b = torch.zeros(n // 2, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.render(got_a.data_ptr(), None, a_opt, s1.cuda_stream)
+        ctx.render(got_b.data_ptr(), None, b_opt, s2.cuda_stream)
+        ctx.render(got_a.data_ptr(), None, a_opt, s2.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
+    ctx.close()
