@@ -86,6 +86,7 @@ struct mi355rt_context {
     uint32_t guided_mult = 16;           // run length = (left in shard) / (guided_mult * waves per shard); 16 measured best at 1/8-image launches
     uint32_t inline_steps = 0;           // 1 when several meshes share the list (many rays miss a mesh's root box: teapot +5..12 %), 0 for a single mesh (semesterbild -10 % otherwise)
     uint32_t trav_min = 24;              // measured optimum 24-32 on semesterbild / teapot (tools/ab_kernel.py)
+    uint32_t walker_waves = 4, pool_patience = 64;   // pool kernel (KERNEL_POOL): walker waves per workgroup, polls before an under-filled pass
     bool have_scene = false;
     mi355rt_settings settings{};
     DevCamera cam{};
@@ -340,24 +341,32 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     uint32_t n_mesh_prims = 0;
     for (const auto& pr : prims) n_mesh_prims += pr.kind == MI355RT_PRIM_MESH;
     const bool has_mesh = n_mesh_prims != 0;
-    ctx->inline_steps = n_mesh_prims >= 2 ? 1u : 0u;
-    if (const char* e = std::getenv("MI355RT_INLINE_STEPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->inline_steps = (uint32_t)v; }
     bool simple_mats = true;                                         // only Lambertian (solid) / Emissive / Null?
     for (uint32_t i = 0; i < sc->n_materials; ++i) {
         const uint32_t k = sc->materials[i].kind;
         simple_mats = simple_mats && (k == MI355RT_MAT_LAMBERT_SOLID || k == MI355RT_MAT_EMISSIVE || k == MI355RT_MAT_NULL);
     }
     ctx->has_mesh = has_mesh;
-    ctx->variant = has_mesh ? KERNEL_STATE_MACHINE : (simple_mats ? KERNEL_LOCKSTEP_SIMPLE : KERNEL_LOCKSTEP);
-    if (const char* e = std::getenv("MI355RT_KERNEL")) {            // A/B override (tools/): 0 lockstep, 1 lockstep+mesh, 2 state machine, 3 lockstep simple
+    // Scenes with meshes: the walk-pool kernel where it was measured to win -- ONE mesh in the list whose whole node array fits
+    // its LDS copy (semesterbild: 51 -> 44 ms at 800x600x256); several meshes / a tree that spills to global memory stay with the
+    // in-wave state machine (teapot: the pool's two round trips per ray and its few loading waves cost +7 %).
+    const bool pool_fits = n_mesh_prims == 1 && nodes.size() <= POOL_NODE_CAP;
+    ctx->variant = has_mesh ? (pool_fits ? KERNEL_POOL : KERNEL_STATE_MACHINE) : (simple_mats ? KERNEL_LOCKSTEP_SIMPLE : KERNEL_LOCKSTEP);
+    if (const char* e = std::getenv("MI355RT_KERNEL")) {            // A/B override (tools/): 0 lockstep, 1 lockstep+mesh, 2 state machine, 3 lockstep simple, 5 walk pool
         const int v = std::atoi(e);
-        const bool ok = (v == KERNEL_LOCKSTEP && !has_mesh) || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE ||
+        const bool ok = (v == KERNEL_LOCKSTEP && !has_mesh) || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || (v == KERNEL_POOL && has_mesh) ||
                         (v == KERNEL_LOCKSTEP_SIMPLE && !has_mesh && simple_mats);
         if (ok) ctx->variant = (uint32_t)v;
     }
+    // Root-box test right at mesh set-up: the pool kernel always (rays that miss the root never leave their wave: 19.6 -> 15.5 ms on
+    // semesterbild); the state machine when several meshes share the list (teapot +5..12 %; a single mesh loses 5-10 %).
+    ctx->inline_steps = (ctx->variant == KERNEL_POOL || n_mesh_prims >= 2) ? 1u : 0u;
+    if (const char* e = std::getenv("MI355RT_INLINE_STEPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->inline_steps = (uint32_t)v; }
     ctx->trav_min = 24;
     if (const char* e = std::getenv("MI355RT_GUIDED_MULT")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->guided_mult = (uint32_t)v; }
     if (const char* e = std::getenv("MI355RT_TRAV_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->trav_min = (uint32_t)v; }
+    if (const char* e = std::getenv("MI355RT_WALKERS")) { const int v = std::atoi(e); if (v >= 4 && v <= 12) ctx->walker_waves = (uint32_t)v; }
+    if (const char* e = std::getenv("MI355RT_POOL_PATIENCE")) { const int v = std::atoi(e); if (v >= 0 && v <= 100000) ctx->pool_patience = (uint32_t)v; }
     return MI355RT_OK;
 }
 
@@ -447,7 +456,9 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
     const bool fixed_aabb = opt && (opt->flags & MI355RT_FLAG_FIXED_AABB) != 0u;
     if (opt && (opt->flags & ~MI355RT_FLAG_FIXED_AABB) != 0u) return fail(MI355RT_ERR_INVALID, "options.flags has unknown bits");
     if (fixed_aabb && rng_mode != MI355RT_RNG_CTR) return fail(MI355RT_ERR_INVALID, "MI355RT_FLAG_FIXED_AABB needs MI355RT_RNG_CTR (the replay mode reproduces the reference as it is)");
-    const uint32_t variant = (fixed_aabb && ctx->has_mesh) ? (uint32_t)KERNEL_STATE_MACHINE_FIXAABB : ctx->variant;   // without a mesh the flag changes nothing
+    const uint32_t variant = !(fixed_aabb && ctx->has_mesh) ? ctx->variant                                              // without a mesh the flag changes nothing
+                           : (ctx->variant == KERNEL_POOL ? (uint32_t)KERNEL_POOL_FIXAABB : (uint32_t)KERNEL_STATE_MACHINE_FIXAABB);
+    const bool pool = variant == KERNEL_POOL || variant == KERNEL_POOL_FIXAABB;
     const uint64_t seed = opt ? opt->seed : 0;
     const uint32_t n_rows = (uint32_t)ctx->rows_host.size();
     if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs[variant]; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
@@ -517,7 +528,8 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.sample0 = s0;
         magic_div((uint32_t)spp, p.spp_mul, p.spp_shift); magic_div(st.width, p.width_mul, p.width_shift);
         p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;
-        p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, LDS_NODE_CAP);
+        p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, pool ? POOL_NODE_CAP : LDS_NODE_CAP);
+        p.walker_waves = ctx->walker_waves; p.pool_patience = ctx->pool_patience;
         ResolveParams r{};
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
         r.spp = (uint32_t)spp; r.inv_spp = 1.0f / (float)s1;                             // renderer.rs:85
@@ -534,7 +546,8 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             const uint32_t waves_per_block = block_threads / 64;
             const uint32_t min_runs = (p.band_samples + BATCH_MIN - 1) / BATCH_MIN;           // never more waves than minimum-size runs
             const uint32_t grid = std::max(1u, std::min(resident, (min_runs + waves_per_block - 1) / waves_per_block));
-            p.guided_div = std::max(1u, ctx->guided_mult * grid * waves_per_block / WORK_SHARDS);
+            const uint32_t claiming_waves = pool ? waves_per_block - ctx->walker_waves : waves_per_block;     // walker waves never claim samples
+            p.guided_div = std::max(1u, ctx->guided_mult * grid * claiming_waves / WORK_SHARDS);
             p.wave_times = nullptr;
             if (ctx->want_wave_times) {
                 ctx->wave_times_n = grid * waves_per_block;
@@ -569,6 +582,9 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         unsigned long long h[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(h, ctx->stats.p, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        unsigned long long watchdog = 0;
+        HIP_TRY(hipMemcpy(&watchdog, ctx->stats.p + 15, sizeof watchdog, hipMemcpyDeviceToHost));
+        if (watchdog != 0) return fail(MI355RT_ERR_HIP, "pool kernel watchdog: a wave waited too long and gave up (image incomplete)");
         stats->render_kernel_ms = render_ms; stats->resolve_kernel_ms = resolve_ms; stats->total_ms = total_ms;
         stats->samples = h[0]; stats->rays = h[1];
         stats->bands = n_bands; stats->grid_blocks = grid_blocks; stats->block_threads = block_threads;

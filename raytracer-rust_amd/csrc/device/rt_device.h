@@ -49,6 +49,7 @@ constexpr uint32_t NODE_MAX_LEAF = 63;                           // triangles pe
 // LDS copy of the hot top of the node array in the state-machine kernel: one 1024-thread workgroup per CU owns the
 // CU's whole 160 KiB (163 840 B); 5 104 nodes x 32 B = 163 328 B.
 constexpr uint32_t LDS_NODE_CAP = 5104;
+constexpr uint32_t POOL_NODE_CAP = 3548;        // pool kernel: 50 KB of its LDS hold the walk requests / results / ring (rt_kernels.hip)
 
 struct DevTri { float v0[3], e1[3], e2[3], n[3]; };
 static_assert(sizeof(DevTri) == 48, "DevTri");
@@ -92,6 +93,8 @@ struct RenderParams {
     uint32_t trav_min;           // state-machine kernel: run BVH rounds while at least this many lanes are walking
     uint32_t inline_steps;       // state-machine kernel: box tests taken right at mesh setup (short walks skip the TRAV round trip)
     uint32_t lds_nodes;          // state-machine kernel: nodes [0, lds_nodes) are read from the workgroup's LDS copy (<= LDS_NODE_CAP)
+    uint32_t walker_waves;       // pool kernel: waves of each workgroup that only walk (4 .. 12 of 16)
+    uint32_t pool_patience;      // pool kernel: polls a producer waits for more results before it runs an under-filled pass
 };
 
 // Which counter-mode kernel serves a scene
@@ -101,7 +104,9 @@ enum : uint32_t {
     KERNEL_STATE_MACHINE = 2,    // wave-voted TRAV / TOP / SHADE blocks (scenes with meshes)
     KERNEL_LOCKSTEP_SIMPLE = 3,  // KERNEL_LOCKSTEP for scenes whose materials are only Lambertian (solid) / Emissive / Null
     KERNEL_STATE_MACHINE_FIXAABB = 4,   // KERNEL_STATE_MACHINE with the opt-in slab test (MI355RT_FLAG_FIXED_AABB)
-    KERNEL_VARIANTS = 5
+    KERNEL_POOL = 5,             // state machine whose BVH walks are served by dedicated walker waves through LDS (scenes with meshes)
+    KERNEL_POOL_FIXAABB = 6,
+    KERNEL_VARIANTS = 7
 };
 
 struct ResolveParams {
@@ -142,6 +147,6 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
 int launch_resolve(const ResolveParams& p, void* stream);
 int launch_render_ref(const RefParams& p, void* stream);
 int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs);
-inline uint32_t block_threads_of(uint32_t variant) { return (variant == 2u || variant == 4u) ? BLOCK_THREADS_SM : BLOCK_THREADS; }   // KERNEL_STATE_MACHINE*
+inline uint32_t block_threads_of(uint32_t variant) { return (variant == 2u || variant >= 4u) ? BLOCK_THREADS_SM : BLOCK_THREADS; }   // KERNEL_STATE_MACHINE*, KERNEL_POOL*
 
 }  // namespace mi355rt

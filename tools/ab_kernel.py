@@ -10,16 +10,17 @@ WL = {"cornell": ("data/scenes/tungsten/cornell-box/scene.json", 800, 600, 256, 
       "teapot": ("data/scenes/tungsten/teapot/scene.json", 800, 600, 64, 30, True)}
 SETTINGS = [("lockstep", {"MI355RT_KERNEL": "1"})] + [(f"sm{t}", {"MI355RT_KERNEL": "2", "MI355RT_TRAV_MIN": str(t)}) for t in (16, 24, 32)] \
          + [("sm24i1", {"MI355RT_KERNEL": "2", "MI355RT_TRAV_MIN": "24", "MI355RT_INLINE_STEPS": "1"})]
-ENV_KEYS = ("MI355RT_KERNEL", "MI355RT_TRAV_MIN", "MI355RT_INLINE_STEPS")
-if os.environ.get("AB_KERNEL_SETTINGS"):     # "name=KERNEL:TRAV_MIN[:INLINE_STEPS],..."
+ENV_KEYS = ("MI355RT_KERNEL", "MI355RT_TRAV_MIN", "MI355RT_INLINE_STEPS", "MI355RT_WALKERS", "MI355RT_POOL_PATIENCE")
+if os.environ.get("AB_KERNEL_SETTINGS"):     # "name=KERNEL:TRAV_MIN[:INLINE_STEPS[:WALKERS[:PATIENCE]]],..."
     SETTINGS = [(kv.split("=")[0], dict(zip(ENV_KEYS, kv.split("=")[1].split(":")))) for kv in os.environ["AB_KERNEL_SETTINGS"].split(",")]
 for wl in sys.argv[1:] or ["semesterbild", "teapot"]:
     path, W, H, spp, depth, skip = WL[wl]
+    spp = int(os.environ.get("AB_SPP", spp))
     sc = host.LoadedScene(os.path.join(ROOT, path), W, H, spp, depth, skip_unknown_primitives=skip)
     out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
     ctxs = {}
     for name, env in SETTINGS:
-        for k in ("MI355RT_KERNEL", "MI355RT_TRAV_MIN", "MI355RT_INLINE_STEPS"): os.environ.pop(k, None)
+        for k in ENV_KEYS: os.environ.pop(k, None)
         os.environ.update(env)
         c = device.Context(0); c.set_scene(sc, sc.camera, sc.settings); ctxs[name] = c
     times = {n: [] for n in ctxs}; info = {}
