@@ -297,6 +297,8 @@ int mi355rt_write_png(const char* path, const uint32_t* packed_rgb, uint32_t wid
 
 /* The pre-gamma f32 image (out_linear_rgb) as a little-endian Portable FloatMap, for parity tooling.  */
 int mi355rt_write_pfm(const char* path, const float* linear_rgb, uint32_t width, uint32_t height);
+/* The same image as an OpenEXR file: scan-line, three 32-bit FLOAT channels (B, G, R), uncompressed, rows top-down. */
+int mi355rt_write_exr(const char* path, const float* linear_rgb, uint32_t width, uint32_t height);
 
 const char* mi355rt_host_last_error(void);
 

@@ -8,6 +8,8 @@
 // never hit), so this builder must not be "improved".  Tie order of Rust's sort_unstable_by is
 // unspecified; ties keep their current slice order here (std::stable_sort).
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -23,29 +25,33 @@ namespace mi355rt_host {
 
 namespace {
 
+// The shape of the tree is a function of the triangle COUNT alone (leaf when n <= 4 or depth >= 25, else split at n / 2,
+// bvh.rs:31-60), so every subtree's node count -- and with it every node's slot in the pre-order array and every leaf's
+// range in the index array -- is known before a single triangle is looked at.  That makes the two halves of a split
+// independent jobs that write into disjoint parts of preallocated arrays: the halves are built by different threads
+// (while threads are free) and the result is, node for node and index for index, the array the serial recursion produces.
 struct Builder {
-    const mi355rt_triangle* tris;
-    std::vector<mi355rt_bvh_node> nodes;
-    std::vector<uint32_t> leaf_indices;
-    uint32_t max_depth = 0;
+    const mi355rt_triangle* tris = nullptr;
+    mi355rt_bvh_node* nodes = nullptr;         // preallocated: subtree_nodes(n, 0)
+    uint32_t* leaf_indices = nullptr;          // preallocated: n
+    std::atomic<uint32_t> max_depth{0};
+    std::atomic<int> spare_threads{0};         // threads that may still be started
 
+    static constexpr size_t MAX_DEPTH = 25, MIN_TRIANGLES_PER_LEAF = 4;
+    static uint32_t subtree_nodes(size_t n, uint32_t depth) {
+        if (n <= MIN_TRIANGLES_PER_LEAF || depth >= MAX_DEPTH) return 1u;
+        const size_t mid = n / 2;
+        return 1u + subtree_nodes(mid, depth + 1) + subtree_nodes(n - mid, depth + 1);
+    }
     static float centroid_axis(const mi355rt_triangle& t, int axis) {
         float s = (t.v0[axis] + t.v1[axis]) + t.v2[axis];
         return s * (1.0f / 3.0f);
     }
 
-    uint32_t make_leaf(uint32_t slot, const uint32_t* idx, size_t n) {
-        nodes[slot].left = nodes[slot].right = 0;
-        nodes[slot].first_index = (uint32_t)leaf_indices.size();
-        nodes[slot].index_count = (uint32_t)n;
-        leaf_indices.insert(leaf_indices.end(), idx, idx + n);
-        return slot;
-    }
-
-    uint32_t build(uint32_t* idx, size_t n, uint32_t depth) {
-        const uint32_t slot = (uint32_t)nodes.size();
-        nodes.emplace_back();
-        if (depth > max_depth) max_depth = depth;
+    // Builds the subtree over idx[0..n) into nodes[slot ...]; its leaves own leaf_indices[index_offset .. index_offset + n).
+    void build(uint32_t* idx, size_t n, uint32_t depth, uint32_t slot, uint32_t index_offset) {
+        uint32_t seen = max_depth.load(std::memory_order_relaxed);
+        while (depth > seen && !max_depth.compare_exchange_weak(seen, depth, std::memory_order_relaxed)) {}
         const float inf = std::numeric_limits<float>::infinity();
         float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
         for (size_t i = 0; i < n; ++i) {
@@ -54,18 +60,30 @@ struct Builder {
             for (const float* v : vs)
                 for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], v[a]); mx[a] = std::fmax(mx[a], v[a]); }
         }
-        std::memcpy(nodes[slot].bmin, mn, 12); std::memcpy(nodes[slot].bmax, mx, 12);
-        const size_t MAX_DEPTH = 25, MIN_TRIANGLES_PER_LEAF = 4;
-        if (n <= MIN_TRIANGLES_PER_LEAF || depth >= MAX_DEPTH) return make_leaf(slot, idx, n);
+        mi355rt_bvh_node& node = nodes[slot];
+        std::memcpy(node.bmin, mn, 12); std::memcpy(node.bmax, mx, 12);
+        if (n <= MIN_TRIANGLES_PER_LEAF || depth >= MAX_DEPTH) {
+            node.left = node.right = 0; node.first_index = index_offset; node.index_count = (uint32_t)n;
+            std::memcpy(leaf_indices + index_offset, idx, n * sizeof(uint32_t));
+            return;
+        }
         const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
         const int axis = (ex > ey && ex > ez) ? 0 : (ey > ez ? 1 : 2);
         std::stable_sort(idx, idx + n, [&](uint32_t a, uint32_t b) { return centroid_axis(tris[a], axis) < centroid_axis(tris[b], axis); });
-        const size_t mid = n / 2;
-        if (mid == 0 || mid == n) return make_leaf(slot, idx, n);
-        const uint32_t l = build(idx, mid, depth + 1);
-        const uint32_t r = build(idx + mid, n - mid, depth + 1);
-        nodes[slot].left = l; nodes[slot].right = r; nodes[slot].first_index = 0; nodes[slot].index_count = 0;
-        return slot;
+        const size_t mid = n / 2;                                              // > 0 and < n because n > 4
+        const uint32_t l = slot + 1u, r = l + subtree_nodes(mid, depth + 1);
+        node.left = l; node.right = r; node.first_index = 0; node.index_count = 0;
+        // the right half on another thread while one is free and the job is worth it, the left half here
+        if (n >= 2048 && spare_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
+            std::thread other([=] { build(idx + mid, n - mid, depth + 1, r, index_offset + (uint32_t)mid); });
+            build(idx, mid, depth + 1, l, index_offset);
+            other.join();
+            spare_threads.fetch_add(1, std::memory_order_relaxed);
+        } else {
+            if (n >= 2048) spare_threads.fetch_add(1, std::memory_order_relaxed);   // undo the reservation that failed
+            build(idx, mid, depth + 1, l, index_offset);
+            build(idx + mid, n - mid, depth + 1, r, index_offset + (uint32_t)mid);
+        }
     }
 };
 
@@ -74,15 +92,41 @@ struct Builder {
 int bvh_build(const mi355rt_triangle* tris, uint32_t n, std::vector<mi355rt_bvh_node>& nodes, std::vector<uint32_t>& indices,
               uint32_t& max_depth) {
     if (!tris || n == 0) return set_error(MI355RT_ERR_INVALID, "bvh_build: no triangles");
-    Builder b; b.tris = tris;
+    return bvh_build_threads(tris, n, nodes, indices, max_depth, 0);
+}
+
+// n_threads: 0 = one per hardware thread (at most 16), 1 = the plain serial recursion.  Any value gives the same arrays.
+int bvh_build_threads(const mi355rt_triangle* tris, uint32_t n, std::vector<mi355rt_bvh_node>& nodes, std::vector<uint32_t>& indices,
+                      uint32_t& max_depth, int n_threads) {
+    if (!tris || n == 0) return set_error(MI355RT_ERR_INVALID, "bvh_build: no triangles");
+    if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads <= 0) n_threads = 1; if (n_threads > 16) n_threads = 16; }
     std::vector<uint32_t> idx(n);
     for (uint32_t i = 0; i < n; ++i) idx[i] = i;          // mesh_object.rs:44
-    b.build(idx.data(), n, 0);
-    nodes.swap(b.nodes); indices.swap(b.leaf_indices); max_depth = b.max_depth;
+    nodes.assign(Builder::subtree_nodes(n, 0), mi355rt_bvh_node{});
+    indices.assign(n, 0u);
+    Builder b; b.tris = tris; b.nodes = nodes.data(); b.leaf_indices = indices.data(); b.spare_threads.store(n_threads - 1);
+    b.build(idx.data(), n, 0, 0u, 0u);
+    max_depth = b.max_depth.load();
     return MI355RT_OK;
 }
 
 }  // namespace mi355rt_host
+
+// Test / tuning hook (not in the public header): the same build with an explicit thread count (1 = serial recursion).
+extern "C" int mi355rt_bvh_build_threads(const mi355rt_triangle* triangles, uint32_t n_triangles, int n_threads, mi355rt_bvh_node* out_nodes,
+                                         uint32_t* out_indices, uint32_t* out_n_nodes, uint32_t* out_max_depth) {
+    using namespace mi355rt_host;
+    std::vector<mi355rt_bvh_node> nodes; std::vector<uint32_t> indices; uint32_t md = 0;
+    int rc;
+    try { rc = bvh_build_threads(triangles, n_triangles, nodes, indices, md, n_threads); }
+    catch (const std::exception& e) { return set_error(MI355RT_ERR_OOM, std::string("bvh_build: ") + e.what()); }
+    if (rc) return rc;
+    if (out_nodes) std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(mi355rt_bvh_node));
+    if (out_indices) std::memcpy(out_indices, indices.data(), indices.size() * sizeof(uint32_t));
+    if (out_n_nodes) *out_n_nodes = (uint32_t)nodes.size();
+    if (out_max_depth) *out_max_depth = md;
+    return MI355RT_OK;
+}
 
 extern "C" int mi355rt_bvh_build(const mi355rt_triangle* triangles, uint32_t n_triangles, mi355rt_bvh_node* out_nodes,
                                  uint32_t* inout_n_nodes, uint32_t* out_indices, uint32_t* inout_n_indices, uint32_t* out_max_depth) {

@@ -18,7 +18,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: %s <scene.json> [-o out.png] [--width W] [--height H] [--spp N] [--max-depth D] [--rng ctr|ref] [--seed S] [--skip-unknown] [--chunk N] [--pfm out.pfm] [--gpus N] [--fix-aabb] [--fix-wo3]\n", argv[0]); return 2; }
-    std::string scene_path = argv[1], out_path = "render_pt.png", pfm_path;
+    std::string scene_path = argv[1], out_path = "render_pt.png", pfm_path, exr_path;
     mi355rt_load_overrides ov{}; mi355rt_options opt{}; uint32_t chunk = 0, gpus = 1;
     opt.abi_version = MI355RT_ABI_VERSION; opt.rng_mode = MI355RT_RNG_CTR; opt.strip_rows = 1; opt.n_parts = 1;
     for (int i = 2; i < argc; ++i) {
@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--skip-unknown")) ov.skip_unknown_primitives = 1;
         else if (!std::strcmp(argv[i], "--chunk")) chunk = (uint32_t)std::atoi(next());
         else if (!std::strcmp(argv[i], "--pfm")) pfm_path = next();
+        else if (!std::strcmp(argv[i], "--exr")) exr_path = next();
         else if (!std::strcmp(argv[i], "--gpus")) gpus = (uint32_t)std::atoi(next());
         else if (!std::strcmp(argv[i], "--fix-aabb")) opt.flags |= MI355RT_FLAG_FIXED_AABB;
         else if (!std::strcmp(argv[i], "--fix-wo3")) ov.wo3_four_index_stride = 1;
@@ -48,7 +49,7 @@ int main(int argc, char** argv) {
     std::printf("Scene loaded. Objects: %u. Image: %ux%u, Samples: %u, Max Depth: %u\n", sc->n_primitives, st->width, st->height,
                 st->samples_per_pixel, st->max_depth);
     std::vector<uint32_t> buffer((size_t)st->width * st->height);
-    std::vector<float> linear(pfm_path.empty() ? 0 : (size_t)st->width * st->height * 3);
+    std::vector<float> linear(pfm_path.empty() && exr_path.empty() ? 0 : (size_t)st->width * st->height * 3);
     float* lin = linear.empty() ? nullptr : linear.data();
     mi355rt_stats stats{};
     std::printf("Rendering frame (%ux%u) with %u AA samples...\n", st->width, st->height, st->samples_per_pixel);
@@ -76,7 +77,8 @@ int main(int argc, char** argv) {
                 stats.total_ms > 0 ? (double)stats.samples / stats.total_ms / 1e3 : 0.0, stats.samples ? (double)stats.rays / (double)stats.samples : 0.0);
     if (mi355rt_write_png(out_path.c_str(), buffer.data(), st->width, st->height) != MI355RT_OK) { std::fprintf(stderr, "%s\n", mi355rt_host_last_error()); mi355rt_scene_free(ls); return 1; }
     std::printf("Image saved as '%s'\n", out_path.c_str());
-    if (lin && mi355rt_write_pfm(pfm_path.c_str(), lin, st->width, st->height) != MI355RT_OK) { std::fprintf(stderr, "%s\n", mi355rt_host_last_error()); mi355rt_scene_free(ls); return 1; }
+    if (lin && !exr_path.empty() && mi355rt_write_exr(exr_path.c_str(), lin, st->width, st->height) != MI355RT_OK) { std::fprintf(stderr, "%s\n", mi355rt_host_last_error()); mi355rt_scene_free(ls); return 1; }
+    if (lin && !pfm_path.empty() && mi355rt_write_pfm(pfm_path.c_str(), lin, st->width, st->height) != MI355RT_OK) { std::fprintf(stderr, "%s\n", mi355rt_host_last_error()); mi355rt_scene_free(ls); return 1; }
     mi355rt_scene_free(ls);
     std::printf("Total %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return 0;

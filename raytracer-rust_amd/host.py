@@ -34,6 +34,8 @@ def lib():
             L.mi355rt_loaded_scene_settings.argtypes = [C.c_void_p]
             L.mi355rt_write_pfm.restype = C.c_int
             L.mi355rt_write_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+            L.mi355rt_write_exr.restype = C.c_int
+            L.mi355rt_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
             L.mi355rt_write_png.restype = C.c_int
             L.mi355rt_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         _lib = L
@@ -122,6 +124,13 @@ def write_pfm(path, linear, width, height):
     a = np.ascontiguousarray(linear, dtype=np.float32)
     assert a.size == width * height * 3
     _check(lib().mi355rt_write_pfm(os.fsencode(path), a.ctypes.data, width, height), "mi355rt_write_pfm")
+
+
+def write_exr(path, linear, width, height):
+    """linear: float32 [height, width, 3] pre-gamma image -> uncompressed 32-bit float OpenEXR (channels B, G, R)."""
+    a = np.ascontiguousarray(linear, dtype=np.float32)
+    assert a.size == width * height * 3
+    _check(lib().mi355rt_write_exr(os.fsencode(path), a.ctypes.data, width, height), "mi355rt_write_exr")
 
 
 def write_png(path, packed, width, height):

@@ -129,3 +129,48 @@ def test_pfm_writer_roundtrip(native, tmp_path):
     assert raw.startswith(header) and len(raw) == len(header) + 5 * 9 * 3 * 4
     got = np.frombuffer(raw[len(header):], dtype="<f4").reshape(5, 9, 3)[::-1]
     assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
+
+
+def _read_exr(raw):
+    """Minimal reader for what mi355rt_write_exr emits, written from the OpenEXR file-layout document (not from the writer):
+    magic, version, attributes until an empty name, offset table, then one chunk per scan line."""
+    import struct
+    assert raw[:4] == bytes([0x76, 0x2F, 0x31, 0x01]) and struct.unpack_from("<I", raw, 4)[0] == 2
+    p, attrs = 8, {}
+    while raw[p] != 0:
+        e = raw.index(b"\0", p); name = raw[p:e].decode(); p = e + 1
+        e = raw.index(b"\0", p); typ = raw[p:e].decode(); p = e + 1
+        size = struct.unpack_from("<i", raw, p)[0]; p += 4
+        attrs[name] = (typ, raw[p:p + size]); p += size
+    p += 1
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    assert attrs["displayWindow"][1] == attrs["dataWindow"][1] and (x0, y0) == (0, 0)
+    W, H = x1 + 1, y1 + 1
+    ch, q, names = attrs["channels"][1], 0, []
+    while ch[q] != 0:
+        e = ch.index(b"\0", q); names.append(ch[q:e].decode()); q = e + 1
+        ptype, _plinear, xs, ys = struct.unpack_from("<iB3xii", ch, q); q += 16
+        assert ptype == 2 and xs == 1 and ys == 1                    # FLOAT, no subsampling
+    assert names == sorted(names) == ["B", "G", "R"]
+    offsets = struct.unpack_from(f"<{H}Q", raw, p)
+    img = np.zeros((H, W, 3), np.float32)
+    for y in range(H):
+        yy, nbytes = struct.unpack_from("<ii", raw, offsets[y])
+        assert yy == y and nbytes == 12 * W
+        rows = np.frombuffer(raw, "<f4", 3 * W, offsets[y] + 8).reshape(3, W)
+        img[y, :, 2], img[y, :, 1], img[y, :, 0] = rows[0], rows[1], rows[2]
+    assert offsets[-1] + 8 + 12 * W == len(raw)
+    return img
+
+
+def test_exr_writer_roundtrip(native, tmp_path):
+    """OpenEXR scan-line file, FLOAT B/G/R, uncompressed: parsed back by an independent reader, bit-preserving."""
+    host, _ = native
+    rng = np.random.default_rng(5)
+    img = rng.standard_normal((7, 13, 3)).astype(np.float32)
+    img[0, 0] = [np.inf, -0.0, np.float32(1e-42)]
+    path = str(tmp_path / "x.exr")
+    host.write_exr(path, img, 13, 7)
+    got = _read_exr(open(path, "rb").read())
+    assert np.array_equal(got.view(np.uint32), img.view(np.uint32))

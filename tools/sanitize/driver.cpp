@@ -169,6 +169,8 @@ int main(int argc, char** argv) {
         std::vector<uint32_t> px(7 * 5, 0x00FF8040u); std::vector<float> lin(7 * 5 * 3, 0.25f);
         expect(mi355rt_write_png((tmp + "/a.png").c_str(), px.data(), 7, 5) == MI355RT_OK, "write_png");
         expect(mi355rt_write_pfm((tmp + "/a.pfm").c_str(), lin.data(), 7, 5) == MI355RT_OK, "write_pfm");
+        expect(mi355rt_write_exr((tmp + "/a.exr").c_str(), lin.data(), 7, 5) == MI355RT_OK, "write_exr");
+        expect(mi355rt_write_exr((tmp + "/a.exr").c_str(), lin.data(), 0, 5) != MI355RT_OK, "write_exr of an empty image");
         expect(mi355rt_write_png((tmp + "/no/dir/a.png").c_str(), px.data(), 7, 5) != MI355RT_OK, "write_png to a missing directory");
         expect(mi355rt_write_png((tmp + "/z.png").c_str(), px.data(), 0, 5) != MI355RT_OK, "write_png of an empty image");
         expect(mi355rt_write_png(nullptr, px.data(), 7, 5) != MI355RT_OK, "write_png null path");
