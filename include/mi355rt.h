@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 1u
+#define MI355RT_ABI_VERSION 2u   /* 2: mi355rt_scene.textures, MI355RT_MAT_TEXTURE */
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MI355RT_OK               0
@@ -71,7 +71,11 @@ enum {
     MI355RT_MAT_ROUGH_GGX       = 6, /* tungsten/materials.rs:306-377 (Ggx)      albedo, p0=roughness, eta, k */
     MI355RT_MAT_ROUGH_BECKMANN  = 7, /* tungsten/materials.rs:306-377 (Beckmann) albedo, p0=roughness, eta, k */
     MI355RT_MAT_NULL            = 8, /* material.rs:229-252 (never scatters, never emits)         */
-    MI355RT_MAT_KIND_COUNT      = 9
+    MI355RT_MAT_TEXTURE         = 9, /* tungsten/parser.rs:199-243 TextureMaterial: Lambert bounce, albedo * texel looked up by the
+                                        hit NORMAL (equirect, nearest);  albedo, p0=h_offset, texture=index into scene.textures.
+                                        No loader path of the reference produces it (parser.rs:315-424 never yields Texture);
+                                        a host that builds its Scene in code can. */
+    MI355RT_MAT_KIND_COUNT      = 10
 };
 
 typedef struct mi355rt_material {      /* 64 bytes */
@@ -82,8 +86,14 @@ typedef struct mi355rt_material {      /* 64 bytes */
     float    p1;
     float    eta[3];                   /* MetalType::ior_k().0, tungsten/materials.rs:115-152      */
     float    k[3];                     /* MetalType::ior_k().1                                     */
-    uint32_t _pad;
+    uint32_t texture;                  /* MI355RT_MAT_TEXTURE: index into mi355rt_scene.textures; 0 otherwise */
 } mi355rt_material;
+
+/* An 8-bit RGBA image as `image::RgbaImage` holds it (parser.rs:201): row-major, row 0 = top, 4 bytes per pixel. */
+typedef struct mi355rt_texture {
+    const uint8_t* rgba8;
+    uint32_t width, height;
+} mi355rt_texture;
 
 /* ---- top-level primitives: the five `impl Hittable` types ------------------------------------ */
 enum {
@@ -145,6 +155,7 @@ typedef struct mi355rt_scene {
     float        miss_color[3];           /* Color::GRAY at HEAD, src/renderer.rs:61             */
     uint32_t     sky_width, sky_height;   /* equirect HDR skybox, src/renderer.rs:40-54; 0 = none */
     const float* sky_rgb;                 /* sky_width*sky_height*3 f32, row 0 = top; NULL = constant miss_color */
+    const mi355rt_texture* textures;      uint32_t n_textures;   /* images of the MI355RT_MAT_TEXTURE materials (ABI 2) */
 } mi355rt_scene;
 
 /* ---- options that have no counterpart in the reference ---------------------------------------- */

@@ -281,6 +281,9 @@ struct Counters {
 // ------------------------------------------------------------------------------------------------
 // MI355RT_FLAG_FIXED_AABB (opt-in, not the reference): set for the duration of one oracle_render call.
 static bool g_fixed_aabb = false;
+// TextureMaterial images of the scene being rendered (set by build_scene / oracle_set_textures before workers start; read-only then)
+static const mi355rt_texture* g_textures = nullptr;
+static uint32_t g_n_textures = 0;
 struct Aabb {
     V3 min, max;
     static Aabb empty() {                                                            // aabb.rs:11-16
@@ -532,6 +535,9 @@ bool build_scene(const mi355rt_scene* in, Scene& sc) {
     sc.prims.assign(in->primitives, in->primitives + in->n_primitives);
     sc.mats.assign(in->materials, in->materials + in->n_materials);
     sc.miss = {in->miss_color[0], in->miss_color[1], in->miss_color[2]};
+    g_textures = in->textures; g_n_textures = in->textures ? in->n_textures : 0u;
+    for (uint32_t i = 0; i < g_n_textures; ++i) if (!g_textures[i].rgba8 || g_textures[i].width == 0 || g_textures[i].height == 0) return false;
+    for (uint32_t i = 0; i < in->n_materials; ++i) if (in->materials[i].kind == MI355RT_MAT_TEXTURE && in->materials[i].texture >= g_n_textures) return false;
     if (in->sky_rgb) {
         if (!in->sky_width || !in->sky_height) return false;
         sc.sky.assign(in->sky_rgb, in->sky_rgb + (size_t)in->sky_width * in->sky_height * 3);
@@ -822,6 +828,22 @@ template <class S> V3 sample_half_vector(bool ggx, V3 normal, float roughness, S
     return to_world(h_local, normal);
 }
 
+// TextureMaterial (tungsten/parser.rs:199-243).  The images of the scene being rendered; set by build_scene() /
+// oracle_set_textures() before any worker thread starts, read-only afterwards.
+static Col texture_value(const mi355rt_material& m, V3 normal_tex) {                  // parser.rs:222-241
+    if (m.texture >= g_n_textures) return BLACK;
+    const mi355rt_texture& t = g_textures[m.texture];
+    float theta = std::acos(normal_tex.y);
+    float phi = std::atan2(normal_tex.z, normal_tex.x) + PI_F;
+    float u = phi / (2.0f * PI_F);
+    float v = theta / PI_F;
+    u = std::fmod(u + m.p0, 1.0f);                                                    // f32 % f32
+    uint32_t x_pixel = rust_as_u32(std::fmax(u, 0.0f) * (float)(t.width - 1));
+    uint32_t y_pixel = rust_as_u32(std::fmax(v, 0.0f) * (float)(t.height - 1));
+    const uint8_t* px = t.rgba8 + 4 * ((size_t)std::min(y_pixel, t.height - 1) * t.width + std::min(x_pixel, t.width - 1));
+    return {(float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f};
+}
+
 // Material::scatter for all kinds.  Returns false for None.
 template <class S>
 bool scatter(const mi355rt_material& m, const Ray& ray_in, const HitRecord& h, S& rng, Ray& scattered, Col& atten) {
@@ -834,6 +856,12 @@ bool scatter(const mi355rt_material& m, const Ray& ray_in, const HitRecord& h, S
         lambert_direction(h, rng, scattered);
         atten = checker_value(m, h.position);
         return true;
+    case MI355RT_MAT_TEXTURE: {                                                       // tungsten/parser.rs:205-243
+        lambert_direction(h, rng, scattered);
+        Col a = {m.albedo[0], m.albedo[1], m.albedo[2]};
+        atten = a * texture_value(m, h.normal);
+        return true;
+    }
     case MI355RT_MAT_METAL: {                                                         // material.rs:87-110
         V3 reflected = mat_reflect(normalized(ray_in.direction), h.normal);
         float fuzz = m.p0;
@@ -1011,6 +1039,7 @@ struct oracle_counters {
 // CTR -> forward throughput), 0 = tail, 1 = forward.
 // Arm (hist != NULL, WALK_HIST_BINS entries, caller-owned) or disarm (NULL) the walk-length histogram.
 void oracle_walk_histogram(unsigned long long* hist) { g_walk_hist = hist; }
+void oracle_set_textures(const mi355rt_texture* textures, uint32_t n) { g_textures = textures; g_n_textures = n; }   // for oracle_scatter_ctr
 // Study hook (tools/nearfirst_study.py): while `out8` is non-null every mesh walk of oracle_render is ALSO run in near-first
 // order and compared; out8 = walks, differ_tri, differ_hitmiss, differ_t_only, nodes_ref, nodes_ordered, tris_ref, tris_ordered.
 void oracle_walk_study(unsigned long long* out8) { g_walk_study_total = reinterpret_cast<WalkStudy*>(out8); }

@@ -5,12 +5,12 @@ the sizes against the values the C compiler reports (`mi355rt_host` exports them
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_IO, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 
 MAT_LAMBERT_SOLID, MAT_LAMBERT_CHECKER, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE, MAT_PLASTIC, \
-    MAT_ROUGH_GGX, MAT_ROUGH_BECKMANN, MAT_NULL = range(9)
+    MAT_ROUGH_GGX, MAT_ROUGH_BECKMANN, MAT_NULL, MAT_TEXTURE = range(10)
 PRIM_SPHERE, PRIM_PLANE, PRIM_QUAD, PRIM_CUBE, PRIM_MESH = range(5)
 RNG_CTR, RNG_REF = 0, 1
 FLAG_FIXED_AABB = 1
@@ -29,7 +29,11 @@ class Settings(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("kind", u32), ("albedo", f32 * 3), ("aux", f32 * 3), ("p0", f32), ("p1", f32),
-                ("eta", f32 * 3), ("k", f32 * 3), ("_pad", u32)]
+                ("eta", f32 * 3), ("k", f32 * 3), ("texture", u32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.POINTER(C.c_uint8)), ("width", u32), ("height", u32)]
 
 
 class Primitive(C.Structure):
@@ -58,7 +62,7 @@ class Scene(C.Structure):
                 ("nodes", C.POINTER(BvhNode)), ("n_nodes", u32),
                 ("tri_indices", C.POINTER(u32)), ("n_tri_indices", u32),
                 ("miss_color", f32 * 3), ("sky_width", u32), ("sky_height", u32),
-                ("sky_rgb", C.POINTER(f32))]
+                ("sky_rgb", C.POINTER(f32)), ("textures", C.POINTER(Texture)), ("n_textures", u32)]
 
 
 class Options(C.Structure):

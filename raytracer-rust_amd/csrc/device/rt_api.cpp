@@ -96,6 +96,7 @@ struct mi355rt_context {
     DevBuf<uint32_t> rows; DevBuf<float> radiance; DevBuf<uint32_t> counters; DevBuf<unsigned long long> stats;
     DevBuf<float> fold_stack;
     DevBuf<float> sky; uint32_t sky_w = 0, sky_h = 0;      // equirect HDR skybox (renderer.rs:40-54); sky_w == 0: none
+    DevBuf<DevTexture> textures; DevBuf<uint32_t> texels;  // MI355RT_MAT_TEXTURE images: table + all texels in one buffer
     DevBuf<unsigned long long> wave_times; uint32_t wave_times_n = 0;   // diagnostics (MI355RT_WAVE_TIMES=1)
     std::vector<uint32_t> rows_host;     // source of the async row-table upload; must outlive the copy
     bool rows_valid = false;             // ctx->rows already holds rows_host (same selection as the last call)
@@ -289,8 +290,18 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         return fail(MI355RT_ERR_INVALID, "skybox too large");
     if (sc->n_primitives && !sc->primitives) return fail(MI355RT_ERR_INVALID, "primitives is null");
     if (sc->n_materials && !sc->materials) return fail(MI355RT_ERR_INVALID, "materials is null");
-    for (uint32_t i = 0; i < sc->n_materials; ++i)
+    if (sc->n_textures && !sc->textures) return fail(MI355RT_ERR_INVALID, "textures is null");
+    uint64_t n_texels = 0;
+    for (uint32_t i = 0; i < sc->n_textures; ++i) {
+        const mi355rt_texture& t = sc->textures[i];
+        if (!t.rgba8 || t.width == 0 || t.height == 0 || t.width >= (1u << 24) || t.height >= (1u << 24)) return fail(MI355RT_ERR_INVALID, "texture: null image or bad size");
+        n_texels += (uint64_t)t.width * t.height;
+    }
+    if (n_texels > (1ull << 30)) return fail(MI355RT_ERR_INVALID, "textures larger than 2^30 texels in total");
+    for (uint32_t i = 0; i < sc->n_materials; ++i) {
         if (sc->materials[i].kind >= MI355RT_MAT_KIND_COUNT) return fail(MI355RT_ERR_INVALID, "material kind");
+        if (sc->materials[i].kind == MI355RT_MAT_TEXTURE && sc->materials[i].texture >= sc->n_textures) return fail(MI355RT_ERR_INVALID, "material texture index");
+    }
 
     std::vector<DevNode> nodes; std::vector<DevTri> tris; std::vector<uint32_t> mesh_roots;
     if (sc->n_meshes && (!sc->meshes || !sc->nodes || !sc->triangles || (!sc->tri_indices && sc->n_tri_indices))) return fail(MI355RT_ERR_INVALID, "mesh arrays are null");
@@ -337,6 +348,20 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         if ((rc = ctx->sky.ensure(nf))) return rc;
         HIP_TRY(hipMemcpy(ctx->sky.p, sc->sky_rgb, nf * sizeof(float), hipMemcpyHostToDevice));
         ctx->sky_w = sc->sky_width; ctx->sky_h = sc->sky_height;
+    }
+    if (sc->n_textures) {
+        if ((rc = ctx->texels.ensure((size_t)n_texels))) return rc;
+        if ((rc = ctx->textures.ensure(sc->n_textures))) return rc;
+        std::vector<DevTexture> table(sc->n_textures);
+        size_t off = 0;
+        for (uint32_t i = 0; i < sc->n_textures; ++i) {
+            const mi355rt_texture& t = sc->textures[i];
+            const size_t n = (size_t)t.width * t.height;
+            HIP_TRY(hipMemcpy(ctx->texels.p + off, t.rgba8, n * 4, hipMemcpyHostToDevice));
+            table[i] = DevTexture{ctx->texels.p + off, t.width, t.height};
+            off += n;
+        }
+        HIP_TRY(hipMemcpy(ctx->textures.p, table.data(), table.size() * sizeof(DevTexture), hipMemcpyHostToDevice));
     }
     uint32_t n_mesh_prims = 0;
     for (const auto& pr : prims) n_mesh_prims += pr.kind == MI355RT_PRIM_MESH;
@@ -415,6 +440,7 @@ void mi355rt_context_destroy(mi355rt_context* ctx) {
     (void)hipSetDevice(ctx->device);
     ctx->prims.release(); ctx->mats.release(); ctx->nodes.release(); ctx->tris.release(); ctx->rows.release();
     ctx->radiance.release(); ctx->counters.release(); ctx->stats.release(); ctx->fold_stack.release(); ctx->wave_times.release(); ctx->sky.release();
+    ctx->textures.release(); ctx->texels.release();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->done) (void)hipEventDestroy(ctx->done);
     for (auto& e : ctx->pool) if (e) (void)hipEventDestroy(e);
@@ -481,7 +507,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         if ((rc = ctx->fold_stack.ensure((size_t)n_rows * std::max(st.max_depth, 1u) * 3))) return rc;
         RefParams rp{};
         rp.prims = ctx->prims.p; rp.mats = ctx->mats.p; rp.nodes = ctx->nodes.p; rp.tris = ctx->tris.p; rp.rows = ctx->rows.p;
-        rp.sky = ctx->sky_w ? ctx->sky.p : nullptr; rp.sky_w = ctx->sky_w; rp.sky_h = ctx->sky_h;
+        rp.sky = ctx->sky_w ? ctx->sky.p : nullptr; rp.sky_w = ctx->sky_w; rp.sky_h = ctx->sky_h; rp.textures = ctx->textures.p;
         rp.out_packed = (uint32_t*)d_out_packed; rp.out_linear = (float*)d_out_linear; rp.fold_stack = ctx->fold_stack.p; rp.stats = ctx->stats.p;
         rp.n_prims = ctx->n_prims; rp.n_mats = ctx->n_mats; rp.n_rows = n_rows;
         std::memcpy(rp.miss, ctx->miss, 12); rp.cam = ctx->cam;
@@ -520,7 +546,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
 
         RenderParams p{};
         p.prims = ctx->prims.p; p.mats = ctx->mats.p; p.nodes = ctx->nodes.p; p.tris = ctx->tris.p; p.rows = ctx->rows.p;
-        p.sky = ctx->sky_w ? ctx->sky.p : nullptr; p.sky_w = ctx->sky_w; p.sky_h = ctx->sky_h;
+        p.sky = ctx->sky_w ? ctx->sky.p : nullptr; p.sky_w = ctx->sky_w; p.sky_h = ctx->sky_h; p.textures = ctx->textures.p;
         p.radiance = ctx->radiance.p; p.stats = ctx->stats.p;
         p.n_prims = ctx->n_prims; p.n_mats = ctx->n_mats;
         std::memcpy(p.miss, ctx->miss, 12); p.cam = ctx->cam;
@@ -640,7 +666,7 @@ int mi355rt_debug_scatter(mi355rt_context* ctx, const void* in_records, uint32_t
     DevBuf<DebugScatterIn> d_in; DevBuf<DebugScatterOut> d_out;
     int rc = d_in.ensure(n); if (!rc) rc = d_out.ensure(n);
     if (!rc && n) {
-        if (hipMemcpy(d_in.p, in, n * sizeof(DebugScatterIn), hipMemcpyHostToDevice) != hipSuccess || launch_debug_scatter(ctx->mats.p, d_in.p, d_out.p, n, nullptr) != 0 ||
+        if (hipMemcpy(d_in.p, in, n * sizeof(DebugScatterIn), hipMemcpyHostToDevice) != hipSuccess || launch_debug_scatter(ctx->mats.p, ctx->textures.p, d_in.p, d_out.p, n, nullptr) != 0 ||
             hipMemcpy(out_records, d_out.p, n * sizeof(DebugScatterOut), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI355RT_ERR_HIP, "debug_scatter");
     }
     d_in.release(); d_out.release();

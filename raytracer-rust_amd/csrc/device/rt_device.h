@@ -37,9 +37,11 @@ struct DevMat {                  // 64 B, same field order as mi355rt_material
     uint32_t kind; float albedo[3];
     float aux[3];  float p0;
     float p1;      float eta[3];
-    float k[3];    uint32_t pad;
+    float k[3];    uint32_t texture;   // MI355RT_MAT_TEXTURE: index into RenderParams.textures
 };
 static_assert(sizeof(DevMat) == 64, "DevMat");
+
+struct DevTexture { const uint32_t* rgba8; uint32_t width, height; };   // one u32 per texel: r | g << 8 | b << 16 | a << 24 (little-endian RGBA8 bytes)
 
 struct DevNode { float bmin[3]; uint32_t a; float bmax[3]; uint32_t b; };
 static_assert(sizeof(DevNode) == 32, "DevNode");
@@ -75,6 +77,7 @@ struct RenderParams {
     const DevPrim* prims; const DevMat* mats; const DevNode* nodes; const DevTri* tris;
     const uint32_t* rows;        // local row -> absolute y
     const float* sky; uint32_t sky_w, sky_h;   // equirect HDR skybox (RGB f32), null = constant miss colour
+    const DevTexture* textures;  // images of the MI355RT_MAT_TEXTURE materials (indices validated at upload)
     float* radiance;             // float4 per band sample
     uint32_t* batch_counter;     // WORK_SHARDS counters (WORK_SHARD_STRIDE words apart): next unclaimed sample of each shard; zeroed per band
     unsigned long long* stats;   // [0] = paths started, [1] = rays traced
@@ -123,6 +126,7 @@ struct RefParams {               // MI355RT_RNG_REF: one lane per selected row
     const DevPrim* prims; const DevMat* mats; const DevNode* nodes; const DevTri* tris;
     const uint32_t* rows;
     const float* sky; uint32_t sky_w, sky_h;
+    const DevTexture* textures;
     uint32_t* out_packed; float* out_linear;
     float* fold_stack;           // n_rows * max_depth * 3 floats (attenuation stack for tail-first folding)
     unsigned long long* stats;
@@ -139,7 +143,7 @@ struct DebugScatterIn { uint32_t material, front_face; float rd[3], p[3], n[3]; 
 struct DebugScatterOut { float scattered, o[3], d[3], atten[3], emitted[3], pad[3]; };                              // 16 words
 struct DebugHitIn { float o[3], d[3]; };                                                                            // d is normalised once (Ray::new)
 struct DebugHitOut { float p[3], n[3], t, material, front_face, hit, pad[2]; };                                     // 12 words
-int launch_debug_scatter(const DevMat* mats, const DebugScatterIn* in, DebugScatterOut* out, uint32_t n, void* stream);
+int launch_debug_scatter(const DevMat* mats, const DevTexture* textures, const DebugScatterIn* in, DebugScatterOut* out, uint32_t n, void* stream);
 int launch_debug_hit(const DevPrim* prims, uint32_t n_prims, const DevNode* nodes, const DevTri* tris, const DebugHitIn* in, DebugHitOut* out, uint32_t n, void* stream);
 
 // launchers (rt_kernels.hip); `stream` is a hipStream_t

@@ -544,8 +544,22 @@ DI float beckmann_lambda(float a, float x) {                                    
 // `diffuse`), diffuse_finish() turns the accepted unit-ball point into the scattered ray (material.rs:54-62).
 // SIMPLE: the scene's materials are only Lambertian (solid) / Emissive / Null (checked on the host), so every
 // scattering material is the Lambert bounce and the other BSDFs -- which set the register peak -- are compiled out.
+// tungsten/parser.rs:222-240: TextureMaterial's texel, looked up by the hit NORMAL (equirectangular, nearest), as a colour in [0, 1]
+DI f3 texture_lookup(const DevTexture* __restrict__ texs, uint32_t index, float h_offset, f3 n) {
+    const DevTexture t = texs[index];
+    const float theta = acosf(n.y);                                                 // :223
+    const float phi = atan2f(n.z, n.x) + PI_F;                                      // :224
+    float u = phi / (2.0f * PI_F);                                                  // :225
+    const float v = theta / PI_F;                                                   // :226
+    u = fmodf(u + h_offset, 1.0f);                                                  // :227  (f32 % f32)
+    const uint32_t xp = as_u32_sat(fmaxf(u, 0.0f) * (float)(t.width - 1u));        // :231
+    const uint32_t yp = as_u32_sat(fmaxf(v, 0.0f) * (float)(t.height - 1u));       // :232
+    const uint32_t px = t.rgba8[(size_t)min(yp, t.height - 1u) * t.width + min(xp, t.width - 1u)];   // :234-236
+    return mk((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);   // :237-241
+}
+
 template <bool SIMPLE, class Rng>
-DI bool scatter_pre(const DevMat* __restrict__ mats, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted, bool& diffuse_out) {
+DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted, bool& diffuse_out) {
     const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
     const uint32_t kind = __float_as_uint(q0.x);
     const f3 albedo = mk(q0.y, q0.z, q0.w);
@@ -565,6 +579,10 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const float4 q0, const Hit&
         int32_t sum = (int32_t)((uint32_t)as_i32_sat(floorf(h.p.x * inv_scale)) + (uint32_t)as_i32_sat(floorf(h.p.y * inv_scale)) +
                                 (uint32_t)as_i32_sat(floorf(h.p.z * inv_scale)));
         if ((sum & 1) != 0) atten = mk(q1.x, q1.y, q1.z);
+        diffuse = true;
+    } else if (kind == MI355RT_MAT_TEXTURE) {                                      // tungsten/parser.rs:205-243
+        const float4 q1 = m4[1];
+        atten = albedo * texture_lookup(texs, __float_as_uint(m4[3].w), q1.w, h.n);
         diffuse = true;
     } else if (kind == MI355RT_MAT_PLASTIC) {                                      // tungsten/materials.rs:29-65
         float ior = m4[1].w;
@@ -664,9 +682,9 @@ DI void diffuse_finish(const Hit& h, f3 p, f3& new_o, f3& new_d) {              
 }
 // Sequential composition (reference-stream replay kernel): random_in_unit_sphere as the plain loop, vec3.rs:54-61.
 template <class Rng>
-DI bool surface_scatter(const DevMat* __restrict__ mats, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted) {
+DI bool surface_scatter(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted) {
     bool diffuse = false;
-    if (!scatter_pre<false>(mats, q0, h, rd_in, rng, new_o, new_d, atten, emitted, diffuse)) return false;
+    if (!scatter_pre<false>(mats, texs, q0, h, rd_in, rng, new_o, new_d, atten, emitted, diffuse)) return false;
     if (diffuse) {
         f3 p; uint32_t j = 0;
         do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));
@@ -860,7 +878,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
             ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
             if (P.max_depth == 0u) { radiance[ps.sidx] = make_float4(0.f, 0.f, 0.f, 0.f); live = false; }   // depth == 0 -> BLACK
         } else {
-            scattered = scatter_pre<SIMPLE>(P.mats, q0, h, ps.rd, ps.rng, no, nd, atten, emitted, diffuse);
+            scattered = scatter_pre<SIMPLE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, no, nd, atten, emitted, diffuse);
         }
     }
     prof.mark(5);
@@ -1455,7 +1473,7 @@ __global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
                 if (!hit_scene<true>(prims, P.n_prims, P.nodes, P.tris, ro, rd, h)) { term = miss_colour(P.sky, P.sky_w, P.sky_h, P.miss, rd); break; }
                 f3 no, nd, atten, emitted;
                 const float4 q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
-                if (!surface_scatter(P.mats, q0, h, rd, rng, no, nd, atten, emitted)) { term = emitted; break; }
+                if (!surface_scatter(P.mats, P.textures, q0, h, rd, rng, no, nd, atten, emitted)) { term = emitted; break; }
                 stack[3 * depth] = atten.x; stack[3 * depth + 1] = atten.y; stack[3 * depth + 2] = atten.z;
                 ro = no; rd = nd; ++depth;
             }
@@ -1475,7 +1493,7 @@ __global__ void __launch_bounds__(64) k_render_ref(const RefParams P) {
 // Diagnostic kernels: one Material::scatter / one HittableList::hit per lane through the device functions above
 // (tests/test_kat_functions.py compares them with independent numpy float32 known answers).
 // ===================================================================================================
-__global__ void __launch_bounds__(64) k_debug_scatter(const DevMat* __restrict__ mats, const DebugScatterIn* __restrict__ in, DebugScatterOut* __restrict__ out, uint32_t n) {
+__global__ void __launch_bounds__(64) k_debug_scatter(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const DebugScatterIn* __restrict__ in, DebugScatterOut* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const DebugScatterIn r = in[i];
@@ -1484,7 +1502,7 @@ __global__ void __launch_bounds__(64) k_debug_scatter(const DevMat* __restrict__
     RngCtr rng; rng.start(r.k0, r.k1, r.x, r.s); rng.ray = r.ray; rng.load_block0();
     const float4 q0 = reinterpret_cast<const float4*>(mats + r.material)[0];
     f3 no = mk(0, 0, 0), nd = mk(0, 0, 0), atten = mk(0, 0, 0), emitted = mk(0, 0, 0);
-    const bool ok = surface_scatter(mats, q0, h, mk(r.rd[0], r.rd[1], r.rd[2]), rng, no, nd, atten, emitted);
+    const bool ok = surface_scatter(mats, texs, q0, h, mk(r.rd[0], r.rd[1], r.rd[2]), rng, no, nd, atten, emitted);
     DebugScatterOut o{};
     o.scattered = ok ? 1.0f : 0.0f;
     o.o[0] = no.x; o.o[1] = no.y; o.o[2] = no.z; o.d[0] = nd.x; o.d[1] = nd.y; o.d[2] = nd.z;
@@ -1511,8 +1529,8 @@ __global__ void __launch_bounds__(64) k_debug_hit(const DevPrim* prims_, uint32_
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
-int launch_debug_scatter(const DevMat* mats, const DebugScatterIn* in, DebugScatterOut* out, uint32_t n, void* stream) {
-    hipLaunchKernelGGL(k_debug_scatter, dim3((n + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, mats, in, out, n);
+int launch_debug_scatter(const DevMat* mats, const DevTexture* textures, const DebugScatterIn* in, DebugScatterOut* out, uint32_t n, void* stream) {
+    hipLaunchKernelGGL(k_debug_scatter, dim3((n + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, mats, textures, in, out, n);
     return (int)hipGetLastError();
 }
 int launch_debug_hit(const DevPrim* prims, uint32_t n_prims, const DevNode* nodes, const DevTri* tris, const DebugHitIn* in, DebugHitOut* out, uint32_t n, void* stream) {

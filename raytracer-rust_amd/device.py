@@ -98,12 +98,14 @@ def render_multi(scene, camera, settings, devices, options=None, want_linear=Tru
     return packed, linear, stats
 
 
-def debug_scatter(materials, records, hip_device=0):
+def debug_scatter(materials, records, hip_device=0, textures=None):
     """Diagnostic: one Material::scatter per record on the device.  materials: ctypes array of abi.Material;
     records: (material index, front_face, rd[3], p[3], n[3], (k0, k1, x, s, ray)).  Returns float32 [n, 10] rows
     (scattered, origin[3], direction[3], attenuation[3]) -- the layout of the oracle's hook."""
     sc = abi.Scene()
     sc.materials, sc.n_materials = materials, len(materials)
+    if textures is not None:
+        sc.textures, sc.n_textures = textures, len(textures)
     sc.miss_color[:] = (0.5, 0.5, 0.5)
     ctx = Context(hip_device)
     try:

@@ -286,3 +286,24 @@ def hit_quad(q, ro, rd, t_min, t_max):
         return None
     n, front = set_face(rd, q["n"])
     return t, p, n, front
+
+
+def texture_value(rgba, h_offset, n):                    # tungsten/parser.rs:222-241 (rgba: uint8 [H, W, 4])
+    """acos / atan2 are evaluated in float64 and rounded once; a normal that lands within an ulp of a texel border may
+    pick the neighbour on another libm -- the test cases keep clear of borders."""
+    H, W = rgba.shape[:2]
+    theta = f32(np.arccos(np.float64(n[1])))
+    phi = f32(f32(np.arctan2(np.float64(n[2]), np.float64(n[0]))) + PI)
+    u = f32(phi / f32(f32(2.0) * PI))
+    v = f32(theta / PI)
+    u = f32(np.fmod(f32(u + h_offset), f32(1.0)))
+    x = int(f32(max(u, f32(0.0)) * f32(W - 1)))
+    y = int(f32(max(v, f32(0.0)) * f32(H - 1)))
+    px = rgba[min(y, H - 1), min(x, W - 1)]
+    return V(f32(px[0]) / f32(255.0), f32(px[1]) / f32(255.0), f32(px[2]) / f32(255.0)), (f32(max(u, f32(0.0)) * f32(W - 1)), f32(max(v, f32(0.0)) * f32(H - 1)))
+
+
+def scatter_texture(albedo, rgba, h_offset, rd, p, n, draws):     # tungsten/parser.rs:205-243
+    o, d = lambert_dir(n, p, draws.unit_ball())
+    tex, _ = texture_value(rgba, h_offset, n)
+    return True, o, d, albedo * tex

@@ -111,6 +111,33 @@ def hit_cases(abi):
     ]
 
 
+def texture_fixture(abi):
+    """An 8 x 4 RGBA8 image with a distinct colour per texel + the material that samples it (h_offset 0.3)."""
+    rgba = np.zeros((4, 8, 4), np.uint8)
+    for y in range(4):
+        for x in range(8):
+            rgba[y, x] = (10 + 30 * x, 20 + 50 * y, 255 - 25 * x - 7 * y, 255)
+    tex = abi.Texture(rgba.ctypes.data_as(C.POINTER(C.c_uint8)), 8, 4)
+    textures = (abi.Texture * 1)(tex)
+    mat = material(abi, abi.MAT_TEXTURE, (0.9, 0.8, 0.7), p0=0.3)
+    mat.texture = 0
+    return rgba, textures, mat
+
+
+def texture_normals():
+    """Unit normals whose equirect coordinates stay at least 2 % of a texel away from every texel border (acos / atan2 ulps
+    cannot change the texel), over all octants and both poles."""
+    rgba = np.zeros((4, 8, 4), np.uint8)
+    rng = np.random.default_rng(11)
+    out = []
+    while len(out) < 48:
+        n = K.normalized(K.V(*rng.normal(size=3)))
+        _, (fx, fy) = K.texture_value(rgba, f32(0.3), n)
+        if min(fx % 1, 1 - fx % 1, fy % 1, 1 - fy % 1) > 0.02:
+            out.append(n)
+    return out + [K.V(0, 1, 0), K.V(0, -1, 0)]
+
+
 def check_scatter(name, want, got, transcendental):
     ok, o, d, a = want
     assert bool(got[0]) == ok, name
@@ -155,6 +182,26 @@ def test_oracle_scatter_equals_the_numpy_known_answers(oracle_mod, abi):
     assert n_checked == 8 * 40
 
 
+def test_oracle_texture_material_equals_the_numpy_known_answers(oracle_mod, abi):
+    """TextureMaterial (parser.rs:199-243): Lambert bounce, attenuation = albedo * the texel the hit NORMAL selects."""
+    rgba, textures, mat = texture_fixture(abi)
+    L = oracle_mod.lib()
+    L.oracle_set_textures.argtypes = [C.POINTER(abi.Texture), C.c_uint32]
+    L.oracle_set_textures(textures, 1)
+    try:
+        seen = set()
+        for i, n in enumerate(texture_normals()):
+            rd, p, ctr = K.normalized(-n + K.V(0.1, 0.05, -0.02)), K.V(0.5, -1.0, 2.0), (7, 9, i, 3, 2)
+            want = K.scatter_texture(K.V(0.9, 0.8, 0.7), rgba, f32(0.3), rd, p, n, K.CtrDraws(*ctr))
+            out = np.zeros(10, np.float32)
+            assert L.oracle_scatter_ctr(C.byref(mat), np.zeros(3, np.float32).ctypes.data, rd.ctypes.data, p.ctypes.data, n.ctypes.data, 1, *ctr, out.ctypes.data) == 0
+            check_scatter("texture", want, out, False)
+            seen.add(tuple(out[7:10]))
+        assert len(seen) >= 20                                  # many different texels were reached
+    finally:
+        L.oracle_set_textures(None, 0)
+
+
 def test_dielectric_total_internal_reflection_takes_no_draw(oracle_mod, abi):
     """Inside glass at a grazing angle: cannot_refract short-circuits the random draw (material.rs:145) and the ray reflects."""
     n = unit((0, 1, 0))
@@ -191,6 +238,14 @@ def test_gpu_scatter_and_hits_equal_the_numpy_known_answers(native, abi):
     got = device.debug_scatter(mats, recs)
     for (name, want, transcendental), g in zip(wants, got):
         check_scatter(name, want, g, transcendental)
+    rgba, textures, tmat = texture_fixture(abi)
+    trecs, twants = [], []
+    for i, n in enumerate(texture_normals()):
+        rd, p, ctr = K.normalized(-n + K.V(0.1, 0.05, -0.02)), K.V(0.5, -1.0, 2.0), (7, 9, i, 3, 2)
+        trecs.append((0, True, rd, p, n, ctr))
+        twants.append(K.scatter_texture(K.V(0.9, 0.8, 0.7), rgba, f32(0.3), rd, p, n, K.CtrDraws(*ctr)))
+    for want, g in zip(twants, device.debug_scatter((abi.Material * 1)(tmat), trecs, textures=textures)):
+        check_scatter("texture", want, g, False)
     for name, sc, rays, expect in hit_cases(abi):
         out = device.debug_hit(sc, [(o, K.V(*d)) for o, d in rays])
         for (o, d), g in zip(rays, out):
