@@ -500,6 +500,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
 
     double render_ms = 0, resolve_ms = 0, total_ms = 0;
     uint32_t n_bands = 0, grid_blocks = 0, block_threads = 0;
+    bool pool_kernel_ran = false;
 
     if (rng_mode == MI355RT_RNG_REF) {
         if (d_accum || s0 != 0 || s1 != st.samples_per_pixel)
@@ -556,6 +557,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;
         p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, pool ? POOL_NODE_CAP : LDS_NODE_CAP);
         p.walker_waves = ctx->walker_waves; p.pool_patience = ctx->pool_patience;
+        pool_kernel_ran = pool;
         ResolveParams r{};
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
         r.spp = (uint32_t)spp; r.inv_spp = 1.0f / (float)s1;                             // renderer.rs:85
@@ -608,8 +610,8 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         unsigned long long h[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(h, ctx->stats.p, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        unsigned long long watchdog = 0;
-        HIP_TRY(hipMemcpy(&watchdog, ctx->stats.p + 15, sizeof watchdog, hipMemcpyDeviceToHost));
+        unsigned long long watchdog = 0;                      // stats[15]: pool kernel only (the stamps build of the state machine counts lanes there)
+        if (pool_kernel_ran) HIP_TRY(hipMemcpy(&watchdog, ctx->stats.p + 15, sizeof watchdog, hipMemcpyDeviceToHost));
         if (watchdog != 0) return fail(MI355RT_ERR_HIP, "pool kernel watchdog: a wave waited too long and gave up (image incomplete)");
         stats->render_kernel_ms = render_ms; stats->resolve_kernel_ms = resolve_ms; stats->total_ms = total_ms;
         stats->samples = h[0]; stats->rays = h[1];
