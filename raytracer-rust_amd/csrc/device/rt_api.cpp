@@ -376,10 +376,11 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     // its LDS copy (semesterbild: 51 -> 44 ms at 800x600x256); several meshes / a tree that spills to global memory stay with the
     // in-wave state machine (teapot: the pool's two round trips per ray and its few loading waves cost +7 %).
     const bool pool_fits = n_mesh_prims == 1 && nodes.size() <= POOL_NODE_CAP;
-    ctx->variant = has_mesh ? (pool_fits ? KERNEL_POOL : KERNEL_STATE_MACHINE) : (simple_mats ? KERNEL_LOCKSTEP_SIMPLE : KERNEL_LOCKSTEP);
+    (void)pool_fits;
+    ctx->variant = has_mesh ? KERNEL_WAVEFRONT : (simple_mats ? KERNEL_LOCKSTEP_SIMPLE : KERNEL_LOCKSTEP);
     if (const char* e = std::getenv("MI355RT_KERNEL")) {            // A/B override (tools/): 0 lockstep, 1 lockstep+mesh, 2 state machine, 3 lockstep simple, 5 walk pool
         const int v = std::atoi(e);
-        const bool ok = (v == KERNEL_LOCKSTEP && !has_mesh) || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || (v == KERNEL_POOL && has_mesh) ||
+        const bool ok = (v == KERNEL_LOCKSTEP && !has_mesh) || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || (v == KERNEL_POOL && has_mesh) || (v == KERNEL_WAVEFRONT && has_mesh) ||
                         (v == KERNEL_LOCKSTEP_SIMPLE && !has_mesh && simple_mats);
         if (ok) ctx->variant = (uint32_t)v;
     }
@@ -483,8 +484,9 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
     if (opt && (opt->flags & ~MI355RT_FLAG_FIXED_AABB) != 0u) return fail(MI355RT_ERR_INVALID, "options.flags has unknown bits");
     if (fixed_aabb && rng_mode != MI355RT_RNG_CTR) return fail(MI355RT_ERR_INVALID, "MI355RT_FLAG_FIXED_AABB needs MI355RT_RNG_CTR (the replay mode reproduces the reference as it is)");
     const uint32_t variant = !(fixed_aabb && ctx->has_mesh) ? ctx->variant                                              // without a mesh the flag changes nothing
-                           : (ctx->variant == KERNEL_POOL ? (uint32_t)KERNEL_POOL_FIXAABB : (uint32_t)KERNEL_STATE_MACHINE_FIXAABB);
+                           : (ctx->variant == KERNEL_POOL ? (uint32_t)KERNEL_POOL_FIXAABB : ctx->variant == KERNEL_WAVEFRONT ? (uint32_t)KERNEL_WAVEFRONT_FIXAABB : (uint32_t)KERNEL_STATE_MACHINE_FIXAABB);
     const bool pool = variant == KERNEL_POOL || variant == KERNEL_POOL_FIXAABB;
+    const bool wavefront = variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB;
     const uint64_t seed = opt ? opt->seed : 0;
     const uint32_t n_rows = (uint32_t)ctx->rows_host.size();
     if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs[variant]; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
@@ -557,7 +559,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;
         p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, pool ? POOL_NODE_CAP : LDS_NODE_CAP);
         p.walker_waves = ctx->walker_waves; p.pool_patience = ctx->pool_patience;
-        pool_kernel_ran = pool;
+        pool_kernel_ran = pool || wavefront;
         ResolveParams r{};
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
         r.spp = (uint32_t)spp; r.inv_spp = 1.0f / (float)s1;                             // renderer.rs:85
@@ -574,7 +576,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             const uint32_t waves_per_block = block_threads / 64;
             const uint32_t min_runs = (p.band_samples + BATCH_MIN - 1) / BATCH_MIN;           // never more waves than minimum-size runs
             const uint32_t grid = std::max(1u, std::min(resident, (min_runs + waves_per_block - 1) / waves_per_block));
-            const uint32_t claiming_waves = pool ? waves_per_block - ctx->walker_waves : waves_per_block;     // walker waves never claim samples
+            const uint32_t claiming_waves = pool ? waves_per_block - ctx->walker_waves : waves_per_block;   // (the wavefront kernel: every wave claims)     // walker waves never claim samples
             p.guided_div = std::max(1u, ctx->guided_mult * grid * claiming_waves / WORK_SHARDS);
             p.wave_times = nullptr;
             if (ctx->want_wave_times) {

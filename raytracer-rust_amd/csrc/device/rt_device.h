@@ -109,7 +109,9 @@ enum : uint32_t {
     KERNEL_STATE_MACHINE_FIXAABB = 4,   // KERNEL_STATE_MACHINE with the opt-in slab test (MI355RT_FLAG_FIXED_AABB)
     KERNEL_POOL = 5,             // state machine whose BVH walks are served by dedicated walker waves through LDS (scenes with meshes)
     KERNEL_POOL_FIXAABB = 6,
-    KERNEL_VARIANTS = 7
+    KERNEL_WAVEFRONT = 7,        // path state in LDS, stages as queues: every pass runs with (nearly) full lanes (scenes with meshes)
+    KERNEL_WAVEFRONT_FIXAABB = 8,
+    KERNEL_VARIANTS = 9
 };
 
 struct ResolveParams {

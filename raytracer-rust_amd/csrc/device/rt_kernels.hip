@@ -1401,6 +1401,250 @@ __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr
 __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_pool_fixaabb(const RenderParams P) { render_ctr_pool<true>(P); }
 
 // ===================================================================================================
+// k_render_ctr_wf -- the path tracer as a WAVEFRONT inside one workgroup: path state lives in LDS, stages are queues.
+//
+// The state machine and the pool kernel keep a path in the registers of ONE lane for its whole life, so every pass of every
+// stage runs with whatever lanes of that wave happen to be in that stage (measured: 0.40 of the lanes on semesterbild).  Here
+// the CU's workgroup owns WF_PATHS path slots in LDS (36 dwords each) and five queues of slot numbers -- FREE, TOP0 (a ray at
+// the head of the list), WALK (a BVH walk in progress), TOP1 (a ray whose walk is back), SHADE.  Every wave loops: look at
+// the queue lengths, pop up to 64 slots of the fullest stage, load what that stage needs, run the stage with (nearly) all
+// lanes busy, store what changed, push each slot to the queue of its next stage.  A path therefore migrates between waves;
+// per path the arithmetic is exactly that of the other kernels (same device functions, same inputs, same order), so images
+// are bit-identical.  Regeneration stays in SHADE: a finished path's slot is refilled from the wave's own work cursor in the
+// same pass, and SHADE passes top themselves up from the FREE queue.
+// Queues: one ring of 1 024 u32 per stage (> WF_PATHS, a slot is in at most one queue), `tail` reserved by ds_add, `head`
+// advanced by ds_cmpst so that a pop never takes more than is there; an entry is written after its ticket is reserved, so a
+// popper may have to wait a few cycles for it (bounded spin) and swaps EMPTY back in.  A push that finds its entry still
+// occupied (a popper stalled for a whole ring revolution -- not observed) raises the error word instead of losing a path.
+// No barrier after start-up.  A wave leaves when its work cursor is exhausted and no path is alive in the workgroup.
+// ===================================================================================================
+constexpr uint32_t WF_PATHS = 960, WF_SLOT_WORDS = 36, WF_RING = 1024, WF_QUEUES = 5;
+constexpr uint32_t WF_EMPTY = 0xFFFFFFFFu, WF_WALK_DONE = 0x80000000u;
+enum : uint32_t { WQ_FREE = 0, WQ_TOP0 = 1, WQ_WALK = 2, WQ_TOP1 = 3, WQ_SHADE = 4, WQ_NONE = 7 };
+constexpr uint32_t WF_LDS_WORDS = 16u + WF_QUEUES * WF_RING + WF_PATHS * WF_SLOT_WORDS;
+static_assert(WF_LDS_WORDS * 4u <= 163840u, "wavefront kernel LDS budget");
+// slot layout (dwords): 0-2 ro | 3 thr.x | 4-6 rd | 7 thr.y | 8 thr.z 9 sidx 10 ray_index 11 k0 | 12 k1 13 x 14 s 15 cursor|WALK_DONE |
+//                       16 cand.t 17 cand.idx 18 cand.aux 19 cand.aux2 | 20-22 walk ro 23 node | 24-26 walk rd 27 best_t |
+//                       28-30 1/d 31 best_tri | 32 len_raw 33 leaf_a 34 leaf_b 35 -
+
+struct WfQueues {
+    uint32_t* ctrl;        // [q] head, [8 + q] tail, [5] live paths, [6] error
+    uint32_t* rings;       // WF_QUEUES x WF_RING
+    // Pop up to `want` entries of queue q for lanes [lane0, lane0 + n): returns n; those lanes get their slot in `id`.
+    DI uint32_t pop(uint32_t q, uint32_t want, uint32_t lane, uint32_t lane0, uint32_t& id, bool& failed) const {
+        uint32_t h = 0, n = 0;
+        if (lane == 0) {
+            for (;;) {
+                h = __hip_atomic_load(&ctrl[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t t = __hip_atomic_load(&ctrl[8u + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                n = min(t - h, want);
+                if (n == 0u || atomicCAS(&ctrl[q], h, h + n) == h) break;
+            }
+        }
+        h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h); n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+        if (lane >= lane0 && lane < lane0 + n) {
+            uint32_t* e = rings + q * WF_RING + ((h + lane - lane0) & (WF_RING - 1u));
+            uint32_t v = WF_EMPTY, spins = 0;
+            for (;;) {                                                   // the pusher reserved this ticket and is about to write it
+                v = atomicExch(e, WF_EMPTY);
+                if (v != WF_EMPTY) break;
+                if (++spins > (1u << 20)) { failed = true; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            id = (v == WF_EMPTY) ? 0u : v;                               // after a failed wait the wave leaves; keep the address in range until then
+        }
+        return n;
+    }
+    DI void push(uint32_t q, bool pred, uint32_t id, uint32_t lane, bool& failed) const {
+        const uint64_t m = __ballot(pred);
+        if (m == 0ull) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the slot's stores are visible before its number is
+        const uint32_t first = (uint32_t)__builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == first) base = atomicAdd(&ctrl[8u + q], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+        if (pred) { if (atomicExch(rings + q * WF_RING + ((base + mbcnt64(m)) & (WF_RING - 1u)), id) != WF_EMPTY) failed = true; }
+    }
+    DI uint32_t count(uint32_t q) const {
+        return __hip_atomic_load(&ctrl[8u + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - __hip_atomic_load(&ctrl[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+template <bool FIXED_AABB>
+DI void render_ctr_wavefront(const RenderParams& P) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_wf[WF_LDS_WORDS];
+    WfQueues Q; Q.ctrl = s_wf; Q.rings = s_wf + 16u;
+    uint32_t* const slots = Q.rings + WF_QUEUES * WF_RING;
+    cprim_t prims = (cprim_t)(P.prims);
+    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = threadIdx.x; i < WF_QUEUES * WF_RING; i += blockDim.x) Q.rings[i] = (i < WF_PATHS) ? i : WF_EMPTY;   // FREE holds every slot
+    if (threadIdx.x < 16u) Q.ctrl[threadIdx.x] = (threadIdx.x == 8u + WQ_FREE) ? WF_PATHS : 0u;
+    __syncthreads();
+
+    WorkCursor wc; wc.init();
+    uint32_t n_paths = 0, n_rays = 0, spins = 0;
+    Prof prof; prof.begin();
+    bool failed = false;
+    for (;;) {
+        if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[6], 1u); break; }
+        if (__hip_atomic_load(&Q.ctrl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
+        const uint32_t cS = Q.count(WQ_SHADE), cT1 = Q.count(WQ_TOP1), cW = Q.count(WQ_WALK), cT0 = Q.count(WQ_TOP0);
+        const uint32_t cF = wc.exhausted() ? 0u : Q.count(WQ_FREE);
+        // the fullest stage (a pass with 64 slots costs what a pass with 5 costs); ties go to the later stage
+        uint32_t stage = WQ_NONE, best = 0;
+        if (min(cT0, 64u) > best) { best = min(cT0, 64u); stage = WQ_TOP0; }
+        if (min(cW, 64u) >= best && cW != 0u) { best = min(cW, 64u); stage = WQ_WALK; }
+        if (min(cT1, 64u) >= best && cT1 != 0u) { best = min(cT1, 64u); stage = WQ_TOP1; }
+        if (min(cS + cF, 64u) >= best && cS + cF != 0u) { best = min(cS + cF, 64u); stage = WQ_SHADE; }
+        if (stage == WQ_NONE) {
+            if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > POOL_SPIN_LIMIT) { failed = true; }
+            continue;
+        }
+        spins = 0;
+        uint32_t id = 0;
+
+        if (stage == WQ_SHADE) {
+            // ---- SHADE + regeneration; lanes left over are topped up with free slots (which only regenerate) ----
+            const uint32_t n = Q.pop(WQ_SHADE, 64u, lane, 0u, id, failed);
+            uint32_t nf = 0;
+            if (n < 64u && !wc.exhausted()) nf = Q.pop(WQ_FREE, 64u - n, lane, n, id, failed);
+            const bool have = lane < n, fill = lane >= n && lane < n + nf;
+            uint32_t* sl = slots + WF_SLOT_WORDS * id;
+            PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
+            ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
+            Cand c; cand_reset(c);
+            if (have) {
+                const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1];
+                const float4 d = reinterpret_cast<const float4*>(sl)[2], e = reinterpret_cast<const float4*>(sl)[3], g = reinterpret_cast<const float4*>(sl)[4];
+                ps.ro = mk(a.x, a.y, a.z); ps.rd = mk(b.x, b.y, b.z); ps.thr = mk(a.w, b.w, d.x);
+                ps.sidx = __float_as_uint(d.y); ps.ray_index = __float_as_uint(d.z); ps.rng.k0 = __float_as_uint(d.w);
+                ps.rng.k1 = __float_as_uint(e.x); ps.rng.x = __float_as_uint(e.y); ps.rng.s = __float_as_uint(e.z); ps.rng.ray = ps.ray_index;
+                c.t = g.x; c.idx = __float_as_uint(g.y); c.aux = g.z; c.aux2 = __float_as_uint(g.w);
+            }
+            bool live = have;
+            const bool any_hit = have && c.idx != CAND_NONE;
+            Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
+            if (any_hit) finish_hit<true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
+            shade_and_regenerate<false>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
+            if (live) {                                                          // a ray to trace: continuing or freshly generated
+                reinterpret_cast<float4*>(sl)[0] = make_float4(ps.ro.x, ps.ro.y, ps.ro.z, ps.thr.x);
+                reinterpret_cast<float4*>(sl)[1] = make_float4(ps.rd.x, ps.rd.y, ps.rd.z, ps.thr.y);
+                reinterpret_cast<float4*>(sl)[2] = make_float4(ps.thr.z, __uint_as_float(ps.sidx), __uint_as_float(ps.ray_index), __uint_as_float(ps.rng.k0));
+                reinterpret_cast<float4*>(sl)[3] = make_float4(__uint_as_float(ps.rng.k1), __uint_as_float(ps.rng.x), __uint_as_float(ps.rng.s), __uint_as_float(0u));
+                reinterpret_cast<float4*>(sl)[4] = make_float4(__builtin_inff(), __uint_as_float(CAND_NONE), 0.f, 0.f);
+            }
+            const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
+            if (lane == 0 && born != died) atomicAdd(&Q.ctrl[5], (uint32_t)(born - died));
+            Q.push(WQ_TOP0, (have || fill) && live, id, lane, failed);
+            Q.push(WQ_FREE, (have || fill) && !live, id, lane, failed);
+            prof.mark(4);
+            continue;
+        }
+
+        if (stage == WQ_WALK) {
+            // ---- WALK: two rounds of eight box tests + the pending leaves; unfinished walks go round again ----
+            const uint32_t n = Q.pop(WQ_WALK, 64u, lane, 0u, id, failed);
+            const bool have = lane < n;
+            uint32_t* sl = slots + WF_SLOT_WORDS * id;
+            MeshTrav m; m.ro = mk(0, 0, 0); m.rd = mk(0, 0, 1); m.ix = m.iy = m.iz = 0.f; m.len_raw = 0.f; m.node = NODE_END; m.best_t = 0.f;
+            m.best_tri = 0xFFFFFFFFu; m.leaf_a = m.leaf_b = 0;
+            uint32_t cursor_word = 0;
+            if (have) {
+                const float4 a = reinterpret_cast<const float4*>(sl)[5], b = reinterpret_cast<const float4*>(sl)[6], d = reinterpret_cast<const float4*>(sl)[7];
+                m.ro = mk(a.x, a.y, a.z); m.node = __float_as_uint(a.w); m.rd = mk(b.x, b.y, b.z); m.best_t = b.w;
+                m.ix = d.x; m.iy = d.y; m.iz = d.z; m.best_tri = __float_as_uint(d.w);
+                m.leaf_a = sl[33]; m.leaf_b = sl[34]; cursor_word = sl[15];
+            }
+            for (int round = 0; round < 2; ++round) {
+                if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (have && m.leaf_b == 0u && m.node != NODE_END) mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, m);
+                if (have && m.leaf_b != 0u) mesh_leaf(t4, EPS, m);
+            }
+            const bool done = have && m.leaf_b == 0u && m.node == NODE_END;
+            if (have) {
+                sl[27] = __float_as_uint(m.best_t); sl[31] = m.best_tri;
+                if (done) sl[15] = cursor_word | WF_WALK_DONE;
+                else { sl[23] = m.node; sl[33] = m.leaf_a; sl[34] = m.leaf_b; }
+            }
+            Q.push(WQ_TOP1, done, id, lane, failed);
+            Q.push(WQ_WALK, have && !done, id, lane, failed);
+            prof.mark(0);
+            continue;
+        }
+
+        {
+            // ---- TOP0 / TOP1: hittable.rs:45-58 from the slot's cursor; a mesh whose root box is hit sends the ray to WALK ----
+            const uint32_t n = Q.pop(stage, 64u, lane, 0u, id, failed);
+            const bool have = lane < n;
+            uint32_t* sl = slots + WF_SLOT_WORDS * id;
+            f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+            Cand c; cand_reset(c);
+            uint32_t cursor = 0xFFFFFFFFu; bool walk_done = false, to_walk = false;
+            if (have) {
+                const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1], g = reinterpret_cast<const float4*>(sl)[4];
+                ro = mk(a.x, a.y, a.z); rd = mk(b.x, b.y, b.z);
+                c.t = g.x; c.idx = __float_as_uint(g.y); c.aux = g.z; c.aux2 = __float_as_uint(g.w);
+                const uint32_t cw = sl[15];
+                cursor = cw & ~WF_WALK_DONE; walk_done = (cw & WF_WALK_DONE) != 0u;
+            }
+            for (uint32_t i = 0; i < P.n_prims; ++i) {
+                const bool mine = have && !to_walk && cursor == i;
+                if (__ballot(mine) == 0ull) continue;
+                cprim_t pr = prims + i;
+                if (mine) {
+                    bool advance = true;
+                    switch (pr->kind) {                                       // wave-uniform: scalar branch
+                        case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ro, rd, EPS, c); break;
+                        case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ro, rd, EPS, c); break;
+                        case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ro, rd, EPS, c); break;
+                        case MI355RT_PRIM_CUBE:   hit_cube(pr, i, ro, rd, EPS, c); break;
+                        default:
+                            if (!walk_done) {
+                                MeshTrav mt; mesh_setup(pr, ro, rd, c.t, mt);
+                                const uint32_t root = mt.node;
+                                mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);       // the root box, here: most rays miss it
+                                if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
+                                else {
+                                    reinterpret_cast<float4*>(sl)[5] = make_float4(mt.ro.x, mt.ro.y, mt.ro.z, __uint_as_float(root));
+                                    reinterpret_cast<float4*>(sl)[6] = make_float4(mt.rd.x, mt.rd.y, mt.rd.z, mt.best_t);
+                                    reinterpret_cast<float4*>(sl)[7] = make_float4(mt.ix, mt.iy, mt.iz, __uint_as_float(0xFFFFFFFFu));
+                                    sl[32] = __float_as_uint(mt.len_raw); sl[33] = 0u; sl[34] = 0u;
+                                    to_walk = true; advance = false;
+                                }
+                            } else {
+                                MeshTrav mt; mt.best_t = __uint_as_float(sl[27]); mt.best_tri = sl[31]; mt.len_raw = __uint_as_float(sl[32]);
+                                mesh_accept(i, mt, rd, EPS, c); walk_done = false;
+                            }
+                            break;
+                    }
+                    if (advance) ++cursor;
+                }
+            }
+            if (have) {
+                reinterpret_cast<float4*>(sl)[4] = make_float4(c.t, __uint_as_float(c.idx), c.aux, __uint_as_float(c.aux2));
+                sl[15] = cursor;
+            }
+            Q.push(WQ_WALK, to_walk, id, lane, failed);
+            Q.push(WQ_SHADE, have && !to_walk, id, lane, failed);
+            prof.mark(1);
+        }
+    }
+    const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
+    if (lane == 0 && P.stats) {
+        atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr);
+        if (failed) atomicAdd(&P.stats[15], 1ull);
+    }
+}
+__global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true>(P); }
+
+// ===================================================================================================
 // k_resolve -- ordered per-pixel sum, 1/spp, sqrt gamma, pack (renderer.rs:100-120), without LDS.
 // One pixel's samples are contiguous in HBM (spp * 16 B apart from the next pixel's) and must be added in sample order.
 // A 16-lane DPP row owns one pixel; lane s of the row loads sample
@@ -1542,6 +1786,8 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
         case KERNEL_LOCKSTEP:        hipLaunchKernelGGL(k_render_ctr_nomesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_MESH:   hipLaunchKernelGGL(k_render_ctr_mesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_SIMPLE: hipLaunchKernelGGL(k_render_ctr_simple, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_WAVEFRONT:       hipLaunchKernelGGL(k_render_ctr_wf, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
+        case KERNEL_WAVEFRONT_FIXAABB: hipLaunchKernelGGL(k_render_ctr_wf_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
         case KERNEL_POOL:            hipLaunchKernelGGL(k_render_ctr_pool, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
         case KERNEL_POOL_FIXAABB:    hipLaunchKernelGGL(k_render_ctr_pool_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
         case KERNEL_STATE_MACHINE_FIXAABB: hipLaunchKernelGGL(k_render_ctr_sm_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
@@ -1563,6 +1809,8 @@ int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs,
                    : variant == KERNEL_LOCKSTEP_MESH ? reinterpret_cast<const void*>(k_render_ctr_mesh)
                    : variant == KERNEL_LOCKSTEP_SIMPLE ? reinterpret_cast<const void*>(k_render_ctr_simple)
                    : variant == KERNEL_STATE_MACHINE_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_sm_fixaabb)
+                   : variant == KERNEL_WAVEFRONT ? reinterpret_cast<const void*>(k_render_ctr_wf)
+                   : variant == KERNEL_WAVEFRONT_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_wf_fixaabb)
                    : variant == KERNEL_POOL ? reinterpret_cast<const void*>(k_render_ctr_pool)
                    : variant == KERNEL_POOL_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_pool_fixaabb)
                                                        : reinterpret_cast<const void*>(k_render_ctr_sm);

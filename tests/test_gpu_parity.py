@@ -104,7 +104,8 @@ def test_state_machine_equals_lockstep_walk(name, native, oracle_mod, abi, monke
     outs = []
     for env in ({"MI355RT_KERNEL": "1"}, {"MI355RT_KERNEL": "2", "MI355RT_TRAV_MIN": "1"}, {"MI355RT_KERNEL": "2", "MI355RT_TRAV_MIN": "64"}, {"MI355RT_KERNEL": "2"},
                 {"MI355RT_KERNEL": "5"}, {"MI355RT_KERNEL": "5", "MI355RT_WALKERS": "9", "MI355RT_TRAV_MIN": "1"},            # walk pool: 4 and 9 walker waves
-                {"MI355RT_KERNEL": "5", "MI355RT_INLINE_STEPS": "0", "MI355RT_POOL_PATIENCE": "500", "MI355RT_TRAV_MIN": "48"}):
+                {"MI355RT_KERNEL": "5", "MI355RT_INLINE_STEPS": "0", "MI355RT_POOL_PATIENCE": "500", "MI355RT_TRAV_MIN": "48"},
+                {"MI355RT_KERNEL": "7"}):                                                                                        # wavefront: path state in LDS, stage queues
         for k in ("MI355RT_KERNEL", "MI355RT_TRAV_MIN", "MI355RT_WALKERS", "MI355RT_INLINE_STEPS", "MI355RT_POOL_PATIENCE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
