@@ -613,7 +613,11 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         HIP_TRY(hipMemcpyAsync(h, ctx->stats.p, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         unsigned long long watchdog = 0;                      // stats[15]: pool kernel only (the stamps build of the state machine counts lanes there)
+#ifndef MI355RT_STAMPS
         if (pool_kernel_ran) HIP_TRY(hipMemcpy(&watchdog, ctx->stats.p + 15, sizeof watchdog, hipMemcpyDeviceToHost));
+#else
+        (void)pool_kernel_ran;
+#endif
         if (watchdog != 0) return fail(MI355RT_ERR_HIP, "pool kernel watchdog: a wave waited too long and gave up (image incomplete)");
         stats->render_kernel_ms = render_ms; stats->resolve_kernel_ms = resolve_ms; stats->total_ms = total_ms;
         stats->samples = h[0]; stats->rays = h[1];

@@ -153,6 +153,10 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
 int launch_resolve(const ResolveParams& p, void* stream);
 int launch_render_ref(const RefParams& p, void* stream);
 int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs);
-inline uint32_t block_threads_of(uint32_t variant) { return (variant == 2u || variant >= 4u) ? BLOCK_THREADS_SM : BLOCK_THREADS; }   // KERNEL_STATE_MACHINE*, KERNEL_POOL*
+#ifndef MI355RT_WF_THREADS
+#define MI355RT_WF_THREADS 768
+#endif
+constexpr uint32_t BLOCK_THREADS_WF = MI355RT_WF_THREADS;   // wavefront kernel: waves per workgroup x 64 (A/B: fewer waves = more path slots per lane)
+inline uint32_t block_threads_of(uint32_t variant) { return variant >= 7u ? BLOCK_THREADS_WF : (variant == 2u || variant >= 4u) ? BLOCK_THREADS_SM : BLOCK_THREADS; }   // KERNEL_WAVEFRONT*, KERNEL_STATE_MACHINE* / KERNEL_POOL*
 
 }  // namespace mi355rt

@@ -344,7 +344,8 @@ struct MeshTrav {
     float best_t; uint32_t best_tri;
     uint32_t leaf_a, leaf_b;   // pending leaf (first triangle, count); leaf_b == 0: none
 };
-DI void mesh_setup(cprim_t pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {   // mesh_object.rs:264-291
+template <class PrimPtr>
+DI void mesh_setup(PrimPtr pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {   // mesh_object.rs:264-291
     m.ro = xform_w2o_point(pr, ro_w);
     f3 rd_raw = xform_w2o_dir(pr, rd_w);
     m.len_raw = len(rd_raw);
@@ -1418,38 +1419,55 @@ __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr
 // occupied (a popper stalled for a whole ring revolution -- not observed) raises the error word instead of losing a path.
 // No barrier after start-up.  A wave leaves when its work cursor is exhausted and no path is alive in the workgroup.
 // ===================================================================================================
-constexpr uint32_t WF_PATHS = 960, WF_SLOT_WORDS = 36, WF_RING = 1024, WF_QUEUES = 5;
-constexpr uint32_t WF_EMPTY = 0xFFFFFFFFu, WF_WALK_DONE = 0x80000000u;
+// Two workgroups of 12 waves per CU (24 waves = 6 per SIMD at 80 VGPRs), 832 slots each: the passes begin with a chain of
+// dependent LDS round trips (pop, ring entry, slot) and the walk reads its nodes from L1/L2, so waves to switch to are worth more
+// than registers.  Measured (semesterbild / teapot, 800x600x64, ms): 1 x 16 waves, 1 728 slots 11.60 / 7.42;  2 x 12 waves,
+// 832 slots each 10.65 / 6.65;  3 x 8 waves, 512 each 11.33 / 6.86;  2 x 14 at 72 VGPRs 14.8 / 9.8 and 2 x 16 at 64 VGPRs
+// 15.3 / 9.0 (spills);  2 x 10 at 96 VGPRs 15.2 / 9.7;  1 x 16 waves with 960 fat slots (36 dwords) 11.6 / 7.3.
+#ifndef MI355RT_WF_PATHS
+#define MI355RT_WF_PATHS 832
+#endif
+#ifndef MI355RT_WF_RING
+#define MI355RT_WF_RING 1024
+#endif
+constexpr uint32_t WF_PATHS = MI355RT_WF_PATHS, WF_SLOT_WORDS = 20, WF_RING = MI355RT_WF_RING, WF_QUEUES = 5;
+constexpr uint32_t WF_EMPTY = 0xFFFFu, WF_WALK_DONE = 0x80000000u;
 enum : uint32_t { WQ_FREE = 0, WQ_TOP0 = 1, WQ_WALK = 2, WQ_TOP1 = 3, WQ_SHADE = 4, WQ_NONE = 7 };
-constexpr uint32_t WF_LDS_WORDS = 16u + WF_QUEUES * WF_RING + WF_PATHS * WF_SLOT_WORDS;
-static_assert(WF_LDS_WORDS * 4u <= 163840u, "wavefront kernel LDS budget");
-// slot layout (dwords): 0-2 ro | 3 thr.x | 4-6 rd | 7 thr.y | 8 thr.z 9 sidx 10 ray_index 11 k0 | 12 k1 13 x 14 s 15 cursor|WALK_DONE |
-//                       16 cand.t 17 cand.idx 18 cand.aux 19 cand.aux2 | 20-22 walk ro 23 node | 24-26 walk rd 27 best_t |
-//                       28-30 1/d 31 best_tri | 32 len_raw 33 leaf_a 34 leaf_b 35 -
+constexpr uint32_t WF_LDS_WORDS = 16u + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
+static_assert(WF_LDS_WORDS * 4u <= 163840u / 2u, "wavefront kernel LDS budget: two workgroups per CU");
+static_assert(WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "a ring holds every slot number");
+// Slot layout, 5 x 16 bytes (the less a path carries, the more paths fit, and the fill of every pass follows from their number:
+// 960 slots of 36 dwords ran SHADE at 37 of 64 lanes):  q0 ro.xyz thr.x | q1 rd.xyz thr.y | q2 thr.z sidx ray_index cursor(+WALK_DONE) |
+// q3 cand.t idx aux aux2 | q4 walk node, best_t, best_tri, -.   Recomputed instead of stored: the RNG key (from sidx), the walk's
+// object-space ray and 1/d (mesh_setup per WALK pass: +3 % instructions), |w2o d| for the (sic) t_world.
 
 struct WfQueues {
     uint32_t* ctrl;        // [q] head, [8 + q] tail, [5] live paths, [6] error
-    uint32_t* rings;       // WF_QUEUES x WF_RING
+    uint16_t* rings;       // WF_QUEUES x WF_RING slot numbers
     // Pop up to `want` entries of queue q for lanes [lane0, lane0 + n): returns n; those lanes get their slot in `id`.
-    DI uint32_t pop(uint32_t q, uint32_t want, uint32_t lane, uint32_t lane0, uint32_t& id, bool& failed) const {
+    // `at_least`: take nothing if fewer are there by now -- every wave reads the same queue lengths, so several decide for the
+    // same stage at once and all but the first would get scraps (measured: SHADE at 38 of 64 lanes); they look again instead.
+    DI uint32_t pop(uint32_t q, uint32_t want, uint32_t at_least, uint32_t lane, uint32_t lane0, uint32_t& id, bool& failed) const {
         uint32_t h = 0, n = 0;
         if (lane == 0) {
             for (;;) {
                 h = __hip_atomic_load(&ctrl[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t t = __hip_atomic_load(&ctrl[8u + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 n = min(t - h, want);
+                if (n < at_least) { n = 0u; break; }
                 if (n == 0u || atomicCAS(&ctrl[q], h, h + n) == h) break;
             }
         }
         h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h); n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
         if (lane >= lane0 && lane < lane0 + n) {
-            uint32_t* e = rings + q * WF_RING + ((h + lane - lane0) & (WF_RING - 1u));
+            volatile uint16_t* e = rings + q * WF_RING + ((h + lane - lane0) & (WF_RING - 1u));
             uint32_t v = WF_EMPTY, spins = 0;
             for (;;) {                                                   // the pusher reserved this ticket and is about to write it
-                v = atomicExch(e, WF_EMPTY);
+                v = *e;
                 if (v != WF_EMPTY) break;
                 if (++spins > (1u << 20)) { failed = true; break; }
             }
+            *e = (uint16_t)WF_EMPTY;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             id = (v == WF_EMPTY) ? 0u : v;                               // after a failed wait the wave leaves; keep the address in range until then
         }
@@ -1463,7 +1481,11 @@ struct WfQueues {
         uint32_t base = 0;
         if (lane == first) base = atomicAdd(&ctrl[8u + q], (uint32_t)__popcll(m));
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
-        if (pred) { if (atomicExch(rings + q * WF_RING + ((base + mbcnt64(m)) & (WF_RING - 1u)), id) != WF_EMPTY) failed = true; }
+        if (pred) {
+            volatile uint16_t* e = rings + q * WF_RING + ((base + mbcnt64(m)) & (WF_RING - 1u));
+            if (*e != WF_EMPTY) failed = true;                           // a popper stalled for a whole ring revolution: never observed, never ignored
+            *e = (uint16_t)id;
+        }
     }
     DI uint32_t count(uint32_t q) const {
         return __hip_atomic_load(&ctrl[8u + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - __hip_atomic_load(&ctrl[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1473,56 +1495,98 @@ struct WfQueues {
 template <bool FIXED_AABB>
 DI void render_ctr_wavefront(const RenderParams& P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_wf[WF_LDS_WORDS];
-    WfQueues Q; Q.ctrl = s_wf; Q.rings = s_wf + 16u;
-    uint32_t* const slots = Q.rings + WF_QUEUES * WF_RING;
+    WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + 16u);
+    uint32_t* const slots = s_wf + 16u + WF_QUEUES * WF_RING / 2u;
     cprim_t prims = (cprim_t)(P.prims);
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t i = threadIdx.x; i < WF_QUEUES * WF_RING; i += blockDim.x) Q.rings[i] = (i < WF_PATHS) ? i : WF_EMPTY;   // FREE holds every slot
+    for (uint32_t i = threadIdx.x; i < WF_QUEUES * WF_RING; i += blockDim.x) Q.rings[i] = (uint16_t)((i < WF_PATHS) ? i : WF_EMPTY);   // FREE holds every slot
     if (threadIdx.x < 16u) Q.ctrl[threadIdx.x] = (threadIdx.x == 8u + WQ_FREE) ? WF_PATHS : 0u;
     __syncthreads();
 
     WorkCursor wc; wc.init();
-    uint32_t n_paths = 0, n_rays = 0, spins = 0;
+    uint32_t n_paths = 0, n_rays = 0, spins = 0, naps = 0;
     Prof prof; prof.begin();
     bool failed = false;
+#ifdef MI355RT_STAMPS
+    unsigned long long w_exec[4] = {0, 0, 0, 0}, w_lanes[4] = {0, 0, 0, 0};    // passes and slots per pass: 0 WALK, 1 TOP1, 2 TOP0, 3 SHADE (+ free fill)
+#define MI355RT_WFCOUNT(i, n) do { w_exec[i] += 1; w_lanes[i] += (n); } while (0)
+#else
+#define MI355RT_WFCOUNT(i, n) do {} while (0)
+#endif
     for (;;) {
         if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[6], 1u); break; }
         if (__hip_atomic_load(&Q.ctrl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
         const uint32_t cS = Q.count(WQ_SHADE), cT1 = Q.count(WQ_TOP1), cW = Q.count(WQ_WALK), cT0 = Q.count(WQ_TOP0);
         const uint32_t cF = wc.exhausted() ? 0u : Q.count(WQ_FREE);
-        // the fullest stage (a pass with 64 slots costs what a pass with 5 costs); ties go to the later stage
+        // A pass costs its instructions whatever its fill, and the stages differ in price (SHADE ~1 800 instructions, WALK ~750,
+        // TOP0 ~700, TOP1 ~400): run the stage whose pass WASTES the fewest lane-instructions, price x empty lanes.  A full queue
+        // wastes nothing; of two thin ones the cheap stage runs and the expensive one keeps filling (measured with "fullest
+        // first": SHADE ran at 39 of 64 lanes while TOP0 ran at 61).  Ties go to the later stage.
+#ifndef MI355RT_WF_POLICY
+#define MI355RT_WF_POLICY 1
+#endif
         uint32_t stage = WQ_NONE, best = 0;
-        if (min(cT0, 64u) > best) { best = min(cT0, 64u); stage = WQ_TOP0; }
-        if (min(cW, 64u) >= best && cW != 0u) { best = min(cW, 64u); stage = WQ_WALK; }
-        if (min(cT1, 64u) >= best && cT1 != 0u) { best = min(cT1, 64u); stage = WQ_TOP1; }
-        if (min(cS + cF, 64u) >= best && cS + cF != 0u) { best = min(cS + cF, 64u); stage = WQ_SHADE; }
+        if (MI355RT_WF_POLICY == 0) {
+            if (min(cT0, 64u) > best) { best = min(cT0, 64u); stage = WQ_TOP0; }
+            if (min(cW, 64u) >= best && cW != 0u) { best = min(cW, 64u); stage = WQ_WALK; }
+            if (min(cT1, 64u) >= best && cT1 != 0u) { best = min(cT1, 64u); stage = WQ_TOP1; }
+            if (min(cS + cF, 64u) >= best && cS + cF != 0u) { best = min(cS + cF, 64u); stage = WQ_SHADE; }
+        } else {
+            uint32_t waste = 0xFFFFFFFFu;
+            if (cT0 != 0u) { const uint32_t w = 7u * (64u - min(cT0, 64u)); if (w <= waste) { waste = w; stage = WQ_TOP0; best = cT0; } }
+            if (cW != 0u) { const uint32_t w = 8u * (64u - min(cW, 64u)); if (w <= waste) { waste = w; stage = WQ_WALK; best = cW; } }
+            if (cT1 != 0u) { const uint32_t w = 4u * (64u - min(cT1, 64u)); if (w <= waste) { waste = w; stage = WQ_TOP1; best = cT1; } }
+            if (cS + cF != 0u) { const uint32_t w = 18u * (64u - min(cS + cF, 64u)); if (w <= waste) { waste = w; stage = WQ_SHADE; best = cS + cF; } }
+        }
         if (stage == WQ_NONE) {
             if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
             __builtin_amdgcn_s_sleep(2);
             if (++spins > POOL_SPIN_LIMIT) { failed = true; }
             continue;
         }
+        // There are fewer path slots (960) than lanes in the workgroup (1 024), so with every wave busy the queues stay short and
+        // the passes run under-filled (measured: SHADE at 37 of 64).  A pass costs its instructions whatever its fill, and the
+        // kernel is issue-bound: while slots are still in flight in OTHER waves (they will land in a queue soon) a wave whose best
+        // queue is short sleeps instead of running a thin pass.  Bounded: after WF_PATIENCE naps it runs what there is.
+#ifndef MI355RT_WF_MINFILL
+#define MI355RT_WF_MINFILL 48
+#endif
+#ifndef MI355RT_WF_PATIENCE
+#define MI355RT_WF_PATIENCE 0                              // measured: any napping loses (semesterbild 64 spp 11.6 -> 12.4..13.0 ms): thin passes still hide latency
+#endif
+        if (best < MI355RT_WF_MINFILL && naps < MI355RT_WF_PATIENCE) {
+            const uint32_t alive = __hip_atomic_load(&Q.ctrl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (alive > cS + cT1 + cW + cT0) { ++naps; __builtin_amdgcn_s_sleep(4); continue; }
+        }
+        naps = 0;
+#ifndef MI355RT_WF_KEEP
+#define MI355RT_WF_KEEP 3                                   // a pop must still find 3/4 of what the decision saw
+#endif
+        auto keep = [](uint32_t seen) { return MI355RT_WF_KEEP == 0 ? 0u : max(1u, seen * MI355RT_WF_KEEP / 4u); };
         spins = 0;
         uint32_t id = 0;
 
         if (stage == WQ_SHADE) {
             // ---- SHADE + regeneration; lanes left over are topped up with free slots (which only regenerate) ----
-            const uint32_t n = Q.pop(WQ_SHADE, 64u, lane, 0u, id, failed);
+            const uint32_t n = Q.pop(WQ_SHADE, 64u, keep(min(cS, 64u)), lane, 0u, id, failed);
             uint32_t nf = 0;
-            if (n < 64u && !wc.exhausted()) nf = Q.pop(WQ_FREE, 64u - n, lane, n, id, failed);
+            if (n < 64u && !wc.exhausted()) nf = Q.pop(WQ_FREE, 64u - n, 0u, lane, n, id, failed);
+            if (n + nf == 0u) continue;
             const bool have = lane < n, fill = lane >= n && lane < n + nf;
+            MI355RT_WFCOUNT(3, n + nf);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
             PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
             ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
             Cand c; cand_reset(c);
             if (have) {
                 const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1];
-                const float4 d = reinterpret_cast<const float4*>(sl)[2], e = reinterpret_cast<const float4*>(sl)[3], g = reinterpret_cast<const float4*>(sl)[4];
+                const float4 d = reinterpret_cast<const float4*>(sl)[2], g = reinterpret_cast<const float4*>(sl)[3];
                 ps.ro = mk(a.x, a.y, a.z); ps.rd = mk(b.x, b.y, b.z); ps.thr = mk(a.w, b.w, d.x);
-                ps.sidx = __float_as_uint(d.y); ps.ray_index = __float_as_uint(d.z); ps.rng.k0 = __float_as_uint(d.w);
-                ps.rng.k1 = __float_as_uint(e.x); ps.rng.x = __float_as_uint(e.y); ps.rng.s = __float_as_uint(e.z); ps.rng.ray = ps.ray_index;
+                ps.sidx = __float_as_uint(d.y); ps.ray_index = __float_as_uint(d.z);
+                start_path(P, ps.sidx, ps.rng, ps.px, ps.py);                   // the RNG key is a function of the sample index
+                ps.rng.ray = ps.ray_index;
                 c.t = g.x; c.idx = __float_as_uint(g.y); c.aux = g.z; c.aux2 = __float_as_uint(g.w);
             }
             bool live = have;
@@ -1533,9 +1597,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             if (live) {                                                          // a ray to trace: continuing or freshly generated
                 reinterpret_cast<float4*>(sl)[0] = make_float4(ps.ro.x, ps.ro.y, ps.ro.z, ps.thr.x);
                 reinterpret_cast<float4*>(sl)[1] = make_float4(ps.rd.x, ps.rd.y, ps.rd.z, ps.thr.y);
-                reinterpret_cast<float4*>(sl)[2] = make_float4(ps.thr.z, __uint_as_float(ps.sidx), __uint_as_float(ps.ray_index), __uint_as_float(ps.rng.k0));
-                reinterpret_cast<float4*>(sl)[3] = make_float4(__uint_as_float(ps.rng.k1), __uint_as_float(ps.rng.x), __uint_as_float(ps.rng.s), __uint_as_float(0u));
-                reinterpret_cast<float4*>(sl)[4] = make_float4(__builtin_inff(), __uint_as_float(CAND_NONE), 0.f, 0.f);
+                reinterpret_cast<float4*>(sl)[2] = make_float4(ps.thr.z, __uint_as_float(ps.sidx), __uint_as_float(ps.ray_index), __uint_as_float(0u));
+                reinterpret_cast<float4*>(sl)[3] = make_float4(__builtin_inff(), __uint_as_float(CAND_NONE), 0.f, 0.f);
             }
             const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
             if (lane == 0 && born != died) atomicAdd(&Q.ctrl[5], (uint32_t)(born - died));
@@ -1547,30 +1610,38 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 
         if (stage == WQ_WALK) {
             // ---- WALK: two rounds of eight box tests + the pending leaves; unfinished walks go round again ----
-            const uint32_t n = Q.pop(WQ_WALK, 64u, lane, 0u, id, failed);
+            const uint32_t n = Q.pop(WQ_WALK, 64u, keep(min(cW, 64u)), lane, 0u, id, failed);
+            if (n == 0u) continue;
             const bool have = lane < n;
+            MI355RT_WFCOUNT(0, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
             MeshTrav m; m.ro = mk(0, 0, 0); m.rd = mk(0, 0, 1); m.ix = m.iy = m.iz = 0.f; m.len_raw = 0.f; m.node = NODE_END; m.best_t = 0.f;
             m.best_tri = 0xFFFFFFFFu; m.leaf_a = m.leaf_b = 0;
             uint32_t cursor_word = 0;
             if (have) {
-                const float4 a = reinterpret_cast<const float4*>(sl)[5], b = reinterpret_cast<const float4*>(sl)[6], d = reinterpret_cast<const float4*>(sl)[7];
-                m.ro = mk(a.x, a.y, a.z); m.node = __float_as_uint(a.w); m.rd = mk(b.x, b.y, b.z); m.best_t = b.w;
-                m.ix = d.x; m.iy = d.y; m.iz = d.z; m.best_tri = __float_as_uint(d.w);
-                m.leaf_a = sl[33]; m.leaf_b = sl[34]; cursor_word = sl[15];
+                const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1], w = reinterpret_cast<const float4*>(sl)[4];
+                cursor_word = sl[11];
+                const DevPrim* __restrict__ pr = P.prims + (cursor_word & ~WF_WALK_DONE);                 // lanes may be in different meshes
+                mesh_setup(pr, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.f, m);                            // the object-space ray, as TOP computed it
+                m.node = __float_as_uint(w.x); m.best_t = w.y; m.best_tri = __float_as_uint(w.z);
             }
-            for (int round = 0; round < 2; ++round) {
+#ifndef MI355RT_WF_ROUNDS
+#define MI355RT_WF_ROUNDS 2
+#endif
+#ifndef MI355RT_WF_STEPS
+#define MI355RT_WF_STEPS 8
+#endif
+            for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
                 if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < MI355RT_WF_STEPS; ++u)
                     if (have && m.leaf_b == 0u && m.node != NODE_END) mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, m);
                 if (have && m.leaf_b != 0u) mesh_leaf(t4, EPS, m);
             }
-            const bool done = have && m.leaf_b == 0u && m.node == NODE_END;
+            const bool done = have && m.leaf_b == 0u && m.node == NODE_END;        // (a pass always ends with its pending leaves tested: leaf_b == 0)
             if (have) {
-                sl[27] = __float_as_uint(m.best_t); sl[31] = m.best_tri;
-                if (done) sl[15] = cursor_word | WF_WALK_DONE;
-                else { sl[23] = m.node; sl[33] = m.leaf_a; sl[34] = m.leaf_b; }
+                reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(m.node), m.best_t, __uint_as_float(m.best_tri), 0.f);
+                if (done) sl[11] = cursor_word | WF_WALK_DONE;
             }
             Q.push(WQ_TOP1, done, id, lane, failed);
             Q.push(WQ_WALK, have && !done, id, lane, failed);
@@ -1580,17 +1651,19 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 
         {
             // ---- TOP0 / TOP1: hittable.rs:45-58 from the slot's cursor; a mesh whose root box is hit sends the ray to WALK ----
-            const uint32_t n = Q.pop(stage, 64u, lane, 0u, id, failed);
+            const uint32_t n = Q.pop(stage, 64u, keep(min(stage == WQ_TOP1 ? cT1 : cT0, 64u)), lane, 0u, id, failed);
+            if (n == 0u) continue;
             const bool have = lane < n;
+            MI355RT_WFCOUNT(stage == WQ_TOP1 ? 1 : 2, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
             f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
             Cand c; cand_reset(c);
             uint32_t cursor = 0xFFFFFFFFu; bool walk_done = false, to_walk = false;
             if (have) {
-                const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1], g = reinterpret_cast<const float4*>(sl)[4];
+                const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1], g = reinterpret_cast<const float4*>(sl)[3];
                 ro = mk(a.x, a.y, a.z); rd = mk(b.x, b.y, b.z);
                 c.t = g.x; c.idx = __float_as_uint(g.y); c.aux = g.z; c.aux2 = __float_as_uint(g.w);
-                const uint32_t cw = sl[15];
+                const uint32_t cw = sl[11];
                 cursor = cw & ~WF_WALK_DONE; walk_done = (cw & WF_WALK_DONE) != 0u;
             }
             for (uint32_t i = 0; i < P.n_prims; ++i) {
@@ -1611,14 +1684,12 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                                 mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);       // the root box, here: most rays miss it
                                 if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
                                 else {
-                                    reinterpret_cast<float4*>(sl)[5] = make_float4(mt.ro.x, mt.ro.y, mt.ro.z, __uint_as_float(root));
-                                    reinterpret_cast<float4*>(sl)[6] = make_float4(mt.rd.x, mt.rd.y, mt.rd.z, mt.best_t);
-                                    reinterpret_cast<float4*>(sl)[7] = make_float4(mt.ix, mt.iy, mt.iz, __uint_as_float(0xFFFFFFFFu));
-                                    sl[32] = __float_as_uint(mt.len_raw); sl[33] = 0u; sl[34] = 0u;
+                                    reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(root), c.t, __uint_as_float(0xFFFFFFFFu), 0.f);
                                     to_walk = true; advance = false;
                                 }
                             } else {
-                                MeshTrav mt; mt.best_t = __uint_as_float(sl[27]); mt.best_tri = sl[31]; mt.len_raw = __uint_as_float(sl[32]);
+                                const float4 w = reinterpret_cast<const float4*>(sl)[4];
+                                MeshTrav mt; mt.best_t = w.y; mt.best_tri = __float_as_uint(w.z); mt.len_raw = len(xform_w2o_dir(pr, rd));   // mesh_object.rs:288, again
                                 mesh_accept(i, mt, rd, EPS, c); walk_done = false;
                             }
                             break;
@@ -1627,8 +1698,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 }
             }
             if (have) {
-                reinterpret_cast<float4*>(sl)[4] = make_float4(c.t, __uint_as_float(c.idx), c.aux, __uint_as_float(c.aux2));
-                sl[15] = cursor;
+                reinterpret_cast<float4*>(sl)[3] = make_float4(c.t, __uint_as_float(c.idx), c.aux, __uint_as_float(c.aux2));
+                sl[11] = cursor;
             }
             Q.push(WQ_WALK, to_walk, id, lane, failed);
             Q.push(WQ_SHADE, have && !to_walk, id, lane, failed);
@@ -1638,11 +1709,20 @@ DI void render_ctr_wavefront(const RenderParams& P) {
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
     if (lane == 0 && P.stats) {
         atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr);
+#ifdef MI355RT_STAMPS
+        for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
+        for (int i = 0; i < 4; ++i) { atomicAdd(&P.stats[8 + 2 * i], w_exec[i]); atomicAdd(&P.stats[9 + 2 * i], w_lanes[i]); }
+#else
         if (failed) atomicAdd(&P.stats[15], 1ull);
+#endif
     }
 }
-__global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true>(P); }
+#ifndef MI355RT_OCC_WF
+#define MI355RT_OCC_WF 6
+#endif
+#define MI355RT_OCC_WFK __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_WF, MI355RT_OCC_WF)))
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true>(P); }
 
 // ===================================================================================================
 // k_resolve -- ordered per-pixel sum, 1/spp, sqrt gamma, pack (renderer.rs:100-120), without LDS.
@@ -1786,8 +1866,8 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
         case KERNEL_LOCKSTEP:        hipLaunchKernelGGL(k_render_ctr_nomesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_MESH:   hipLaunchKernelGGL(k_render_ctr_mesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_SIMPLE: hipLaunchKernelGGL(k_render_ctr_simple, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
-        case KERNEL_WAVEFRONT:       hipLaunchKernelGGL(k_render_ctr_wf, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
-        case KERNEL_WAVEFRONT_FIXAABB: hipLaunchKernelGGL(k_render_ctr_wf_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
+        case KERNEL_WAVEFRONT:       hipLaunchKernelGGL(k_render_ctr_wf, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
+        case KERNEL_WAVEFRONT_FIXAABB: hipLaunchKernelGGL(k_render_ctr_wf_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_POOL:            hipLaunchKernelGGL(k_render_ctr_pool, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
         case KERNEL_POOL_FIXAABB:    hipLaunchKernelGGL(k_render_ctr_pool_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
         case KERNEL_STATE_MACHINE_FIXAABB: hipLaunchKernelGGL(k_render_ctr_sm_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
