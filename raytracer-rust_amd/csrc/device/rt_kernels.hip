@@ -1626,7 +1626,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 m.node = __float_as_uint(w.x); m.best_t = w.y; m.best_tri = __float_as_uint(w.z);
             }
 #ifndef MI355RT_WF_ROUNDS
-#define MI355RT_WF_ROUNDS 2
+#define MI355RT_WF_ROUNDS 3                                 // rounds x steps (ms, semesterbild / teapot 64 spp): 1x8 11.8 / 7.5, 2x8 10.7 / 6.6, 3x8 10.4 / 6.4, 4x8 10.4 / 6.3, 8x8 10.7 / 6.6, 3x12 10.7 / 6.4
 #endif
 #ifndef MI355RT_WF_STEPS
 #define MI355RT_WF_STEPS 8
