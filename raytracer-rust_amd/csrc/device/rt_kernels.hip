@@ -1415,8 +1415,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr
 // same pass, and SHADE passes top themselves up from the FREE queue.
 // Queues: one ring of 1 024 u32 per stage (> WF_PATHS, a slot is in at most one queue), `tail` reserved by ds_add, `head`
 // advanced by ds_cmpst so that a pop never takes more than is there; an entry is written after its ticket is reserved, so a
-// popper may have to wait a few cycles for it (bounded spin) and swaps EMPTY back in.  A push that finds its entry still
-// occupied (a popper stalled for a whole ring revolution -- not observed) raises the error word instead of losing a path.
+// popper may have to wait a few cycles for it (bounded spin) and writes EMPTY back; a pusher whose entry is still occupied (the
+// popper of the previous ring revolution has reserved it but not read it yet) waits for that popper, so no slot number is ever lost.
 // No barrier after start-up.  A wave leaves when its work cursor is exhausted and no path is alive in the workgroup.
 // ===================================================================================================
 // Two workgroups of 12 waves per CU (24 waves = 6 per SIMD at 80 VGPRs), 832 slots each: the passes begin with a chain of
@@ -1425,15 +1425,25 @@ __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr
 // 832 slots each 10.65 / 6.65;  3 x 8 waves, 512 each 11.33 / 6.86;  2 x 14 at 72 VGPRs 14.8 / 9.8 and 2 x 16 at 64 VGPRs
 // 15.3 / 9.0 (spills);  2 x 10 at 96 VGPRs 15.2 / 9.7;  1 x 16 waves with 960 fat slots (36 dwords) 11.6 / 7.3.
 #ifndef MI355RT_WF_PATHS
-#define MI355RT_WF_PATHS 832
+#define MI355RT_WF_PATHS 768
 #endif
 #ifndef MI355RT_WF_RING
 #define MI355RT_WF_RING 1024
 #endif
-constexpr uint32_t WF_PATHS = MI355RT_WF_PATHS, WF_SLOT_WORDS = 20, WF_RING = MI355RT_WF_RING, WF_QUEUES = 5;
+constexpr uint32_t WF_PATHS = MI355RT_WF_PATHS, WF_SLOT_WORDS = 20, WF_RING = MI355RT_WF_RING, WF_QUEUES = 8, WF_CTRL_WORDS = 32;
 constexpr uint32_t WF_EMPTY = 0xFFFFu, WF_WALK_DONE = 0x80000000u;
-enum : uint32_t { WQ_FREE = 0, WQ_TOP0 = 1, WQ_WALK = 2, WQ_TOP1 = 3, WQ_SHADE = 4, WQ_NONE = 7 };
-constexpr uint32_t WF_LDS_WORDS = 16u + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
+// SHADE is four queues, one per material class of the hit: a pass whose slots all take the same branch of Material::scatter pays
+// for that branch only (a mixed pass pays for the sum of all branches that any of its lanes takes).
+enum : uint32_t { WQ_FREE = 0, WQ_TOP0 = 1, WQ_WALK = 2, WQ_TOP1 = 3,
+                  WQ_SHADE = 4,      // + class: 0 terminal (miss / emissive / null: the path ends, the slot regenerates), 1 diffuse (Lambert,
+                                     //          checker, texture, plastic), 2 rough conductor, 3 specular (metal, dielectric)
+                  WQ_NONE = 15 };
+DI uint32_t shade_class(uint32_t kind) {
+    return (kind == MI355RT_MAT_EMISSIVE || kind == MI355RT_MAT_NULL) ? 0u
+         : (kind == MI355RT_MAT_ROUGH_GGX || kind == MI355RT_MAT_ROUGH_BECKMANN) ? 2u
+         : (kind == MI355RT_MAT_METAL || kind == MI355RT_MAT_DIELECTRIC) ? 3u : 1u;
+}
+constexpr uint32_t WF_LDS_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
 static_assert(WF_LDS_WORDS * 4u <= 163840u / 2u, "wavefront kernel LDS budget: two workgroups per CU");
 static_assert(WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "a ring holds every slot number");
 // Slot layout, 5 x 16 bytes (the less a path carries, the more paths fit, and the fill of every pass follows from their number:
@@ -1442,7 +1452,7 @@ static_assert(WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "a ring holds every slo
 // object-space ray and 1/d (mesh_setup per WALK pass: +3 % instructions), |w2o d| for the (sic) t_world.
 
 struct WfQueues {
-    uint32_t* ctrl;        // [q] head, [8 + q] tail, [5] live paths, [6] error
+    uint32_t* ctrl;        // [q] head, [8 + q] tail, [16] live paths, [17] error
     uint16_t* rings;       // WF_QUEUES x WF_RING slot numbers
     // Pop up to `want` entries of queue q for lanes [lane0, lane0 + n): returns n; those lanes get their slot in `id`.
     // `at_least`: take nothing if fewer are there by now -- every wave reads the same queue lengths, so several decide for the
@@ -1483,7 +1493,11 @@ struct WfQueues {
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
         if (pred) {
             volatile uint16_t* e = rings + q * WF_RING + ((base + mbcnt64(m)) & (WF_RING - 1u));
-            if (*e != WF_EMPTY) failed = true;                           // a popper stalled for a whole ring revolution: never observed, never ignored
+            // The entry of ticket T is free once the popper of ticket T - WF_RING has read it and written EMPTY back.  That popper
+            // exists (a ring holds more entries than there are slots, so ticket T - WF_RING was popped before T could be reserved);
+            // if it has been held up between reserving and reading, wait for it instead of overwriting its entry.
+            uint32_t spins = 0;
+            while (*e != WF_EMPTY) { if (++spins > (1u << 20)) { failed = true; break; } }
             *e = (uint16_t)id;
         }
     }
@@ -1495,14 +1509,14 @@ struct WfQueues {
 template <bool FIXED_AABB>
 DI void render_ctr_wavefront(const RenderParams& P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_wf[WF_LDS_WORDS];
-    WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + 16u);
-    uint32_t* const slots = s_wf + 16u + WF_QUEUES * WF_RING / 2u;
+    WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + WF_CTRL_WORDS);
+    uint32_t* const slots = s_wf + WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u;
     cprim_t prims = (cprim_t)(P.prims);
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = threadIdx.x; i < WF_QUEUES * WF_RING; i += blockDim.x) Q.rings[i] = (uint16_t)((i < WF_PATHS) ? i : WF_EMPTY);   // FREE holds every slot
-    if (threadIdx.x < 16u) Q.ctrl[threadIdx.x] = (threadIdx.x == 8u + WQ_FREE) ? WF_PATHS : 0u;
+    if (threadIdx.x < WF_CTRL_WORDS) Q.ctrl[threadIdx.x] = (threadIdx.x == 8u + WQ_FREE) ? WF_PATHS : 0u;
     __syncthreads();
 
     WorkCursor wc; wc.init();
@@ -1516,9 +1530,11 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #define MI355RT_WFCOUNT(i, n) do {} while (0)
 #endif
     for (;;) {
-        if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[6], 1u); break; }
-        if (__hip_atomic_load(&Q.ctrl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
-        const uint32_t cS = Q.count(WQ_SHADE), cT1 = Q.count(WQ_TOP1), cW = Q.count(WQ_WALK), cT0 = Q.count(WQ_TOP0);
+        if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[17], 1u); break; }
+        if (__hip_atomic_load(&Q.ctrl[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
+        const uint32_t cT1 = Q.count(WQ_TOP1), cW = Q.count(WQ_WALK), cT0 = Q.count(WQ_TOP0);
+        const uint32_t cS0 = Q.count(WQ_SHADE), cS1 = Q.count(WQ_SHADE + 1u), cS2 = Q.count(WQ_SHADE + 2u), cS3 = Q.count(WQ_SHADE + 3u);
+        const uint32_t cS = cS0 + cS1 + cS2 + cS3;
         const uint32_t cF = wc.exhausted() ? 0u : Q.count(WQ_FREE);
         // A pass costs its instructions whatever its fill, and the stages differ in price (SHADE ~1 800 instructions, WALK ~750,
         // TOP0 ~700, TOP1 ~400): run the stage whose pass WASTES the fewest lane-instructions, price x empty lanes.  A full queue
@@ -1528,20 +1544,19 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #define MI355RT_WF_POLICY 1
 #endif
         uint32_t stage = WQ_NONE, best = 0;
-        if (MI355RT_WF_POLICY == 0) {
-            if (min(cT0, 64u) > best) { best = min(cT0, 64u); stage = WQ_TOP0; }
-            if (min(cW, 64u) >= best && cW != 0u) { best = min(cW, 64u); stage = WQ_WALK; }
-            if (min(cT1, 64u) >= best && cT1 != 0u) { best = min(cT1, 64u); stage = WQ_TOP1; }
-            if (min(cS + cF, 64u) >= best && cS + cF != 0u) { best = min(cS + cF, 64u); stage = WQ_SHADE; }
-        } else {
+        {
             uint32_t waste = 0xFFFFFFFFu;
-            if (cT0 != 0u) { const uint32_t w = 7u * (64u - min(cT0, 64u)); if (w <= waste) { waste = w; stage = WQ_TOP0; best = cT0; } }
-            if (cW != 0u) { const uint32_t w = 8u * (64u - min(cW, 64u)); if (w <= waste) { waste = w; stage = WQ_WALK; best = cW; } }
-            if (cT1 != 0u) { const uint32_t w = 4u * (64u - min(cT1, 64u)); if (w <= waste) { waste = w; stage = WQ_TOP1; best = cT1; } }
-            if (cS + cF != 0u) { const uint32_t w = 18u * (64u - min(cS + cF, 64u)); if (w <= waste) { waste = w; stage = WQ_SHADE; best = cS + cF; } }
+            auto consider = [&](uint32_t q, uint32_t n, uint32_t price) {
+                if (n == 0u) return;
+                const uint32_t w = price * (64u - min(n, 64u));
+                if (w <= waste) { waste = w; stage = q; best = n; }
+            };
+            consider(WQ_TOP0, cT0, 7u); consider(WQ_WALK, cW, 11u); consider(WQ_TOP1, cT1, 4u);
+            consider(WQ_SHADE + 3u, cS3, 5u); consider(WQ_SHADE + 2u, cS2, 10u); consider(WQ_SHADE + 1u, cS1, 8u);
+            consider(WQ_SHADE, cS0 + cF, 5u);                           // terminal class: free slots ride along (both only regenerate)
         }
         if (stage == WQ_NONE) {
-            if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
+            if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
             __builtin_amdgcn_s_sleep(2);
             if (++spins > POOL_SPIN_LIMIT) { failed = true; }
             continue;
@@ -1557,7 +1572,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #define MI355RT_WF_PATIENCE 0                              // measured: any napping loses (semesterbild 64 spp 11.6 -> 12.4..13.0 ms): thin passes still hide latency
 #endif
         if (best < MI355RT_WF_MINFILL && naps < MI355RT_WF_PATIENCE) {
-            const uint32_t alive = __hip_atomic_load(&Q.ctrl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t alive = __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (alive > cS + cT1 + cW + cT0) { ++naps; __builtin_amdgcn_s_sleep(4); continue; }
         }
         naps = 0;
@@ -1568,11 +1583,12 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         spins = 0;
         uint32_t id = 0;
 
-        if (stage == WQ_SHADE) {
-            // ---- SHADE + regeneration; lanes left over are topped up with free slots (which only regenerate) ----
-            const uint32_t n = Q.pop(WQ_SHADE, 64u, keep(min(cS, 64u)), lane, 0u, id, failed);
+        if (stage >= WQ_SHADE) {
+            // ---- SHADE (one material class) + regeneration; a terminal-class pass is topped up with free slots (which only regenerate) ----
+            const uint32_t seen = stage == WQ_SHADE ? cS0 : stage == WQ_SHADE + 1u ? cS1 : stage == WQ_SHADE + 2u ? cS2 : cS3;
+            const uint32_t n = Q.pop(stage, 64u, seen == 0u ? 0u : keep(min(seen, 64u)), lane, 0u, id, failed);
             uint32_t nf = 0;
-            if (n < 64u && !wc.exhausted()) nf = Q.pop(WQ_FREE, 64u - n, 0u, lane, n, id, failed);
+            if (stage == WQ_SHADE && n < 64u && !wc.exhausted()) nf = Q.pop(WQ_FREE, 64u - n, 0u, lane, n, id, failed);
             if (n + nf == 0u) continue;
             const bool have = lane < n, fill = lane >= n && lane < n + nf;
             MI355RT_WFCOUNT(3, n + nf);
@@ -1601,7 +1617,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 reinterpret_cast<float4*>(sl)[3] = make_float4(__builtin_inff(), __uint_as_float(CAND_NONE), 0.f, 0.f);
             }
             const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
-            if (lane == 0 && born != died) atomicAdd(&Q.ctrl[5], (uint32_t)(born - died));
+            if (lane == 0 && born != died) atomicAdd(&Q.ctrl[16], (uint32_t)(born - died));
             Q.push(WQ_TOP0, (have || fill) && live, id, lane, failed);
             Q.push(WQ_FREE, (have || fill) && !live, id, lane, failed);
             prof.mark(4);
@@ -1701,8 +1717,12 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 reinterpret_cast<float4*>(sl)[3] = make_float4(c.t, __uint_as_float(c.idx), c.aux, __uint_as_float(c.aux2));
                 sl[11] = cursor;
             }
+            // the list is done: route the slot by the material class of its hit, so that SHADE passes are homogeneous
+            uint32_t cls = 0u;
+            if (have && !to_walk && c.idx != CAND_NONE) cls = shade_class(P.mats[P.prims[c.idx].material].kind);
             Q.push(WQ_WALK, to_walk, id, lane, failed);
-            Q.push(WQ_SHADE, have && !to_walk, id, lane, failed);
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) Q.push(WQ_SHADE + k, have && !to_walk && cls == k, id, lane, failed);
             prof.mark(1);
         }
     }
