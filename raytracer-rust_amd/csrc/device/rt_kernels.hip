@@ -1501,6 +1501,16 @@ struct WfQueues {
             *e = (uint16_t)id;
         }
     }
+    // Every lane with `pred` pushes its slot to ITS queue `q` (lanes may name different queues): one reservation per queue present.
+    DI void push_each(bool pred, uint32_t q, uint32_t id, uint32_t lane, bool& failed) const {
+        uint64_t rem = __ballot(pred);
+        while (rem != 0ull) {
+            const uint32_t qq = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)__builtin_ctzll(rem));
+            const bool mine = pred && q == qq;
+            push(qq, mine, id, lane, failed);
+            rem &= ~__ballot(mine);
+        }
+    }
     DI uint32_t count(uint32_t q) const {
         return __hip_atomic_load(&ctrl[8u + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - __hip_atomic_load(&ctrl[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -1720,9 +1730,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             // the list is done: route the slot by the material class of its hit, so that SHADE passes are homogeneous
             uint32_t cls = 0u;
             if (have && !to_walk && c.idx != CAND_NONE) cls = shade_class(P.mats[P.prims[c.idx].material].kind);
-            Q.push(WQ_WALK, to_walk, id, lane, failed);
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) Q.push(WQ_SHADE + k, have && !to_walk && cls == k, id, lane, failed);
+            Q.push_each(have, to_walk ? (uint32_t)WQ_WALK : WQ_SHADE + cls, id, lane, failed);
             prof.mark(1);
         }
     }
