@@ -185,7 +185,7 @@ typedef struct mi355rt_options {
     uint32_t strip_rows, n_parts, part;
     uint32_t flags;             /* MI355RT_FLAG_*; 0 reproduces the reference                      */
     uint64_t workspace_bytes; /* cap for the per-sample radiance workspace in HBM; 0 = default (32 GiB,
-                                 of which only width*rows*spp*16 bytes are allocated)             */
+                                 of which only width*rows*spp*12 bytes are allocated)             */
 } mi355rt_options;
 
 typedef struct mi355rt_stats {

@@ -527,13 +527,13 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         const uint64_t spp = s1 - s0;                                 // samples per pixel in THIS launch
         const uint64_t total_pixels = (uint64_t)n_rows * st.width;
         uint64_t ws_cap = (opt && opt->workspace_bytes) ? opt->workspace_bytes : (32ull << 30);   // 288 GB of HBM: default = the 2^31-sample band limit; only what a band needs is allocated
-        uint64_t max_samples = std::min<uint64_t>(ws_cap / 16, (1ull << 31) - 2 * BATCH_MAX);
-        if (max_samples < spp) return fail(MI355RT_ERR_INVALID, "workspace_bytes too small for one pixel (needs spp * 16 bytes)");
+        uint64_t max_samples = std::min<uint64_t>(ws_cap / 12, (1ull << 31) - 2 * BATCH_MAX);
+        if (max_samples < spp) return fail(MI355RT_ERR_INVALID, "workspace_bytes too small for one pixel (needs spp * 12 bytes)");
         uint64_t band_pixels_max = std::min<uint64_t>(max_samples / spp, total_pixels);
         // Only what a band needs is allocated.  When even that does not fit (another tenant on the GPU, a small device),
         // halve the band and try again: more, smaller bands give the same image (tiling invariance), just more launches.
         for (;;) {
-            rc = ctx->radiance.ensure((size_t)(band_pixels_max * spp * 4));
+            rc = ctx->radiance.ensure((size_t)(band_pixels_max * spp * 3));
             if (rc != MI355RT_ERR_OOM || band_pixels_max <= 1) break;
             (void)hipGetLastError();
             band_pixels_max = (band_pixels_max + 1) / 2;

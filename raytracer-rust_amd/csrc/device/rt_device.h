@@ -16,7 +16,7 @@
 //                             normal (the same f32 subtractions bvh.rs:95-96 performs per test)
 //   rows[n_rows]         4 B  local output row -> absolute image row y (the RNG key)
 //   sky[h*w*3]           4 B  optional equirect HDR skybox, per-lane nearest-texel gather on miss
-//   radiance[band]      16 B  one float4 per path (sample-major inside a pixel), written once by
+//   radiance[band]      12 B  three floats per path (sample-major inside a pixel), written once by
 //                             the path tracer and read once by the resolve kernel
 #pragma once
 #include <stdint.h>
@@ -78,7 +78,7 @@ struct RenderParams {
     const uint32_t* rows;        // local row -> absolute y
     const float* sky; uint32_t sky_w, sky_h;   // equirect HDR skybox (RGB f32), null = constant miss colour
     const DevTexture* textures;  // images of the MI355RT_MAT_TEXTURE materials (indices validated at upload)
-    float* radiance;             // float4 per band sample
+    float* radiance;             // 3 floats per band sample
     uint32_t* batch_counter;     // WORK_SHARDS counters (WORK_SHARD_STRIDE words apart): next unclaimed sample of each shard; zeroed per band
     unsigned long long* stats;   // [0] = paths started, [1] = rays traced
     unsigned long long* wave_times;  // diagnostic builds only: WAVE_TIME_WORDS u64 per wave; null otherwise
@@ -115,7 +115,7 @@ enum : uint32_t {
 };
 
 struct ResolveParams {
-    const float* radiance;       // float4 per band sample
+    const float* radiance;       // 3 floats per band sample
     uint32_t* out_packed;        // local pixels, 0x00RRGGBB
     float* out_linear;           // local pixels * 3, may be null
     float* accum;                // optional running per-pixel sums (float4 per local pixel): progressive rendering

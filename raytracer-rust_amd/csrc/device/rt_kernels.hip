@@ -248,6 +248,17 @@ DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     float denom = dot(n, rd);
     float t = (pr->d[12] - dot(n, ro)) / denom;
     const bool candidate = !(fabsf(denom) < EPS) && !(t <= t_min || t >= c.t);
+#ifndef MI355RT_QUAD_BRANCHY                               // branch-free form: cornell 19.74 -> 19.61 ms, veach-mis +-0 (with the 4-register candidate)
+    // every lane runs the parallelogram test; the candidate is updated by two selects (no exec-mask region, no copies per level)
+    f3 hit_pos = ro + rd * t;
+    f3 v = hit_pos - mk(pr->d[0], pr->d[1], pr->d[2]);
+    float l0 = dot(v, mk(pr->d[3], pr->d[4], pr->d[5])) * pr->d[13];
+    float l1 = dot(v, mk(pr->d[6], pr->d[7], pr->d[8])) * pr->d[14];
+    const float lo = -EPS, hi = 1.0f + EPS;
+    const bool acc = candidate && ((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi));
+    c.t = acc ? t : c.t; c.idx = acc ? i : c.idx;
+    return acc;
+#else
     if (!candidate) return false;
     f3 hit_pos = ro + rd * t;
     f3 v = hit_pos - mk(pr->d[0], pr->d[1], pr->d[2]);
@@ -257,6 +268,7 @@ DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     if (!((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi))) return false;
     c.t = t; c.idx = i;
     return true;
+#endif
 }
 
 // glam Mat4 * Vec4 pieces on the DevPrim cube/mesh record (see rt_device.h for the layout).  PrimPtr is the wave-uniform
@@ -850,7 +862,8 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 template <bool SIMPLE>
 DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
-    float4* __restrict__ radiance = reinterpret_cast<float4*>(P.radiance);
+    struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
+    Rad* __restrict__ radiance = reinterpret_cast<Rad*>(P.radiance);
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         f3 term = mk(0.f, 0.f, 0.f); bool fin = false;
@@ -861,7 +874,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
             if (kind == MI355RT_MAT_EMISSIVE) { term = mk(q0.y, q0.z, q0.w); fin = true; }   // scatter -> None, emitted = colour
             else if (kind == MI355RT_MAT_NULL) fin = true;
         }
-        if (fin) { const f3 L = ps.thr * term; radiance[ps.sidx] = make_float4(L.x, L.y, L.z, 0.0f); live = false; }
+        if (fin) { const f3 L = ps.thr * term; radiance[ps.sidx] = Rad{L.x, L.y, L.z}; live = false; }
     }
     prof.mark(2);
     bool fresh = false;
@@ -877,7 +890,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
             const float v = ((float)ps.py + ps.rng.jitter_v()) / (float)P.height;        // renderer.rs:97
             camera_ray(P.cam, u, v, ps.ro, ps.rd);                                       // renderer.rs:99
             ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
-            if (P.max_depth == 0u) { radiance[ps.sidx] = make_float4(0.f, 0.f, 0.f, 0.f); live = false; }   // depth == 0 -> BLACK
+            if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
         } else {
             scattered = scatter_pre<SIMPLE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, no, nd, atten, emitted, diffuse);
         }
@@ -890,11 +903,11 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
             ps.thr = ps.thr * atten; ps.ro = no; ps.rd = nd; ++ps.ray_index;
             if (ps.ray_index == P.max_depth) {                                           // next level has depth == 0 (renderer.rs:20-22)
                 const f3 L = ps.thr * mk(0.f, 0.f, 0.f);
-                radiance[ps.sidx] = make_float4(L.x, L.y, L.z, 0.0f); live = false;
+                radiance[ps.sidx] = Rad{L.x, L.y, L.z}; live = false;
             }
         } else {                                                                         // absorbed: scatter -> None (renderer.rs:35)
             const f3 L = ps.thr * emitted;
-            radiance[ps.sidx] = make_float4(L.x, L.y, L.z, 0.0f); live = false;
+            radiance[ps.sidx] = Rad{L.x, L.y, L.z}; live = false;
         }
     }
     if (live) ++n_rays;
@@ -1772,14 +1785,16 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveParams P) {
     const uint32_t p = wave * 4u + (lane >> 4);                  // this row's pixel within the band
     const bool valid = p < P.band_pixels;
     const size_t o = (size_t)P.band_pixel0 + p;
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f* __restrict__ rad = reinterpret_cast<const v4f*>(P.radiance) + (size_t)(valid ? p : 0u) * P.spp;
+    const float* __restrict__ rad = P.radiance + 3u * (size_t)(valid ? p : 0u) * P.spp;     // 3 floats per sample
     float4* __restrict__ accum = reinterpret_cast<float4*>(P.accum);
     f3 acc = mk(0.f, 0.f, 0.f);                                  // meaningful in lane 0 of the row
     if (accum && P.accum_load && valid) { const float4 a = accum[o]; acc = mk(a.x, a.y, a.z); }
     for (uint32_t c = 0; c < P.spp; c += 16u) {
         f3 x = mk(0.f, 0.f, 0.f);
-        if (valid && c + s < P.spp) { const v4f v = __builtin_nontemporal_load(rad + c + s); x = mk(v.x, v.y, v.z); }
+        if (valid && c + s < P.spp) {
+            const float* q = rad + 3u * (c + s);
+            x = mk(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2));
+        }
         if (s == 0u) x = acc + x;                                 // renderer.rs:100 goes on where the previous 16 samples stopped
         f3 t = x;
 #pragma unroll

@@ -76,7 +76,7 @@ def test_tiling_is_bit_invariant(native, oracle_mod, abi):
     p, l, _ = device.render(sc, sc.camera, sc.settings, opt)
     assert np.array_equal(p, full[10:31]) and np.array_equal(l.view(np.uint32), full_lin[10:31].view(np.uint32))
     # tiny workspace -> many bands (one band = 3 pixels)
-    opt = abi.Options.make(workspace_bytes=3 * 4 * 16)
+    opt = abi.Options.make(workspace_bytes=3 * 4 * 12)      # 4 spp x 12 B per sample x 3 pixels
     p, l, st = device.render(sc, sc.camera, sc.settings, opt)
     assert st.bands == (64 * 48 + 2) // 3
     assert np.array_equal(p, full) and np.array_equal(l.view(np.uint32), full_lin.view(np.uint32))

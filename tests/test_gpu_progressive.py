@@ -16,7 +16,7 @@ def _one_shot(device, abi, sc, spp, opt):
 @pytest.mark.parametrize("name,chunks,opt_kw", [
     ("cornell", (3, 5, 8), {}),
     ("cornell", (1, 1, 30), {"strip_rows": 3, "n_parts": 2, "part": 1}),
-    ("teapot", (4, 2, 6), {"workspace_bytes": 64 * 48 * 16 * 3}),          # several pixel bands per chunk
+    ("teapot", (4, 2, 6), {"workspace_bytes": 64 * 48 * 12 * 3}),          # several pixel bands per chunk
     ("veach", (7, 9), {"row_begin": 5, "row_end": 29}),
 ])
 def test_chunked_samples_equal_one_shot(name, chunks, opt_kw, native, oracle_mod, abi):

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def test_out_of_memory_for_the_workspace_falls_back_to_smaller_bands(native, abi):
     host, device = native
-    W, H, spp = 800, 600, 1024                                       # 491.5 M samples -> a 7.9 GB one-band workspace
+    W, H, spp = 800, 600, 1024                                       # 491.5 M samples -> a 5.9 GB one-band workspace (12 B per sample)
     sc = host.LoadedScene(SCENES["cornell"], W, H, spp, 8)
     n = W * H
     ref = torch.zeros(n, dtype=torch.int32, device="cuda")
@@ -27,14 +27,14 @@ def test_out_of_memory_for_the_workspace_falls_back_to_smaller_bands(native, abi
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free, _total = torch.cuda.mem_get_info()
-    hog = torch.empty(max(free - (3 << 30), 0), dtype=torch.uint8, device="cuda")      # leave about 3 GB
+    hog = torch.empty(max(free - (2 << 30), 0), dtype=torch.uint8, device="cuda")      # leave about 2 GB
     try:
         out = torch.zeros(n, dtype=torch.int32, device="cuda")
         ctx = device.Context(0)
         ctx.set_scene(sc, sc.camera, sc.settings)
         st = ctx.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
         ctx.close()
-        assert st.bands >= 4 and st.samples == st0.samples and st.rays == st0.rays
+        assert st.bands >= 4 and st.samples == st0.samples and st.rays == st0.rays       # 5.9 -> 2.95 -> 1.47 GB
         assert torch.equal(out, ref)
     finally:
         del hog

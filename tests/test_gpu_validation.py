@@ -69,7 +69,7 @@ def test_settings_and_options_are_validated(native, oracle_mod, abi):
     assert _render_rc(device, abi, sc, cam, st, o)[0] == abi.ERR_INVALID
     o = abi.Options.make(row_begin=4, row_end=2)
     assert _render_rc(device, abi, sc, cam, st, o)[0] == abi.ERR_INVALID
-    o = abi.Options.make(workspace_bytes=8)              # less than one pixel's spp * 16 bytes
+    o = abi.Options.make(workspace_bytes=8)              # less than one pixel's spp * 12 bytes
     rc, msg = _render_rc(device, abi, sc, cam, st, o)
     assert rc == abi.ERR_INVALID and "workspace" in msg
     sky = abi.Scene(); C.memmove(C.byref(sky), C.byref(sc.c), C.sizeof(abi.Scene)); sky.sky_width = 4; sky.sky_height = 2
