@@ -256,7 +256,7 @@ def main():
             "metric": f"Msamples/s (pixels x spp / s) at {W}x{H}x{spp}spp; 1/2/4/8-GPU scaling",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": f"synthetic (the reference's own {os.path.basename(os.path.dirname(path)) or path} scene file; no external data)",
+            "vs_baseline": None, "dtype": "f32", "data": f"synthetic (the reference's own scene file {path}; no external data)",
             "config": {"workload": args.workload, "scene": path, "width": W, "height": H, "spp": spp, "max_bounces": depth,
                        "rng": "ctr (Philox4x32-10 per ray)", "parallelism": f"row strips of {plan.strip_rows} dealt round-robin over {world} GPU(s)"
                        + (f", RCCL {rtdist.collective_name(rehearse)} of the packed rows" if world > 1 else ""),
