@@ -1,0 +1,44 @@
+"""CPU-only checks of bench.py's bookkeeping: the counters file is only trusted for the kernel sources it was taken on, and the
+committed file matches the committed sources (so the driver's bench line says "pmc": "fresh")."""
+import importlib
+import json
+import os
+import sys
+
+from conftest import ROOT, pkg
+
+sys.path.insert(0, ROOT)
+
+
+def test_committed_pmc_counters_belong_to_the_committed_kernel_sources():
+    build = pkg("build")
+    doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
+    assert doc["kernel_hash"] == build.kernel_hash(), "re-run tools/pmc_collect.py on the GPU box after changing the kernels"
+    bench = importlib.import_module("bench")
+    for wl in bench.WORKLOADS:
+        rec, state = bench.load_pmc(wl, build.kernel_hash())
+        assert state == "fresh" and rec["valu_wave_insts_per_step"] > 0 and rec["hbm_bytes_per_step"] > 0 and 0 < rec["valu_lane_utilisation"] <= 1
+        # every fraction bench.py can print from these counters is physical: issue rate below the peak for any plausible kernel time
+        assert rec["kernel"].startswith("k_render_ctr")
+
+
+def test_stale_or_missing_counters_are_reported_not_used(tmp_path, monkeypatch):
+    bench = importlib.import_module("bench")
+    p = tmp_path / "pmc.json"
+    monkeypatch.setattr(bench, "PMC_FILE", str(p))
+    assert bench.load_pmc("cornell-box-800x600x256-d30", "abc") == (None, "absent")
+    p.write_text(json.dumps({"kernel_hash": "other", "workloads": {"cornell-box-800x600x256-d30": {"valu_wave_insts_per_step": 1}}}))
+    assert bench.load_pmc("cornell-box-800x600x256-d30", "abc") == (None, "stale")
+    p.write_text(json.dumps({"kernel_hash": "abc", "workloads": {}}))
+    assert bench.load_pmc("cornell-box-800x600x256-d30", "abc") == (None, "absent")
+    p.write_text("{not json")
+    assert bench.load_pmc("cornell-box-800x600x256-d30", "abc") == (None, "unreadable")
+
+
+def test_cpu_thread_count_respects_an_override(monkeypatch):
+    bench = importlib.import_module("bench")
+    monkeypatch.setenv("MI355RT_CPU_THREADS", "3")
+    assert bench.usable_cores()[0] == 3
+    monkeypatch.delenv("MI355RT_CPU_THREADS")
+    n, why = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1) and "affinity" in why
