@@ -199,3 +199,59 @@ def test_texture_material_scene_matches_the_oracle(native, oracle_mod, abi):
     mats[1].texture = 5
     with pytest.raises(device.RenderError):
         device.render(sc, cam, st, abi.Options.make())
+
+
+@pytest.mark.parametrize("kernel", ["7", "2", "1"])
+def test_caller_built_bvh_with_fat_leaves(kernel, native, oracle_mod, abi, monkeypatch):
+    """The BVH crosses the ABI in the reference's shape, so a caller may hand over any tree -- also leaves with more triangles than
+    the device's 6-bit leaf count holds.  Such a leaf keeps its box test as an inner node in front of a chain of chunk leaves with
+    infinite bounds (rt_api.cpp, flatten_meshes).  One mesh of 150 triangles under (a) the tree the host builder makes, (b) ONE leaf
+    holding all 150, (c) a root over a 100-triangle and a 50-triangle leaf: each must match the oracle walking the SAME tree, bit for
+    bit, in every mesh kernel.  (The trees need not agree with each other: a tight child box can reject a grazing hit its parent
+    box lets through, reference behaviour that both sides reproduce.)"""
+    import ctypes as C
+    from fuzz_scenes import random_scene
+    host, device = native
+    monkeypatch.setenv("MI355RT_KERNEL", kernel)
+    st = abi.Settings(48, 36, 4, 6)
+    keep = []                                                           # ctypes arrays the scene points into
+
+    def scene():
+        return random_scene(abi, host, 77, exact_only=True, n_prims=6, mesh_tris=150, only_kinds=[abi.PRIM_MESH, abi.PRIM_QUAD, abi.PRIM_SPHERE])
+
+    def both(sc):
+        got = device.render(sc, sc.camera, st, abi.Options.make())
+        op, ol, cnt = oracle_mod.render(sc, sc.camera, st, abi.Options.make())
+        assert np.array_equal(got[1].view(np.uint32), ol.view(np.uint32)) and np.array_equal(got[0], op)
+        return got
+
+    base = both(scene())
+
+    def with_tree(make_nodes, idx_of):
+        sc = scene()
+        c = getattr(sc, "c", sc)
+        assert c.n_meshes >= 1
+        mesh = c.meshes[0]
+        n = mesh.triangle_count
+        assert n > 63
+        root = c.nodes[mesh.first_node]
+        nodes, idx = make_nodes(list(root.bmin), list(root.bmax), n), idx_of(n)
+        others_nodes = [c.nodes[i] for i in range(c.n_nodes)]
+        others_idx = [c.tri_indices[i] for i in range(c.n_tri_indices)]
+        all_nodes = (abi.BvhNode * (len(others_nodes) + len(nodes)))(*others_nodes, *nodes)
+        all_idx = (C.c_uint32 * (len(others_idx) + len(idx)))(*others_idx, *idx)
+        keep.extend([sc, all_nodes, all_idx])
+        c.nodes, c.n_nodes = C.cast(all_nodes, C.POINTER(abi.BvhNode)), len(all_nodes)
+        c.tri_indices, c.n_tri_indices = C.cast(all_idx, C.POINTER(C.c_uint32)), len(all_idx)
+        mesh.first_node, mesh.node_count, mesh.first_index, mesh.index_count = len(others_nodes), len(nodes), len(others_idx), len(idx)
+        return both(sc)
+
+    def node(bmin, bmax, left=0, right=0, first=0, count=0):
+        b = abi.BvhNode(); b.bmin[:] = bmin; b.bmax[:] = bmax; b.left, b.right, b.first_index, b.index_count = left, right, first, count
+        return b
+
+    one_leaf = with_tree(lambda lo, hi, n: [node(lo, hi, first=0, count=n)], lambda n: list(range(n)))
+    two = with_tree(lambda lo, hi, n: [node(lo, hi, left=1, right=2), node(lo, hi, first=0, count=100), node(lo, hi, first=100, count=n - 100)],
+                    lambda n: list(range(n)))
+    # the mesh is visible at all: the images are not just sky, and the three trees give practically the same picture
+    assert np.abs(one_leaf[1] - base[1]).mean() < 1e-3 and np.abs(two[1] - base[1]).mean() < 1e-3
