@@ -324,12 +324,14 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
             if (p.kind == MI355RT_PRIM_CUBE) cube_normal_table(d.d);
             if (p.kind == MI355RT_PRIM_MESH) {
                 if (p.mesh >= sc->n_meshes) return fail(MI355RT_ERR_INVALID, "primitive mesh index");
-                d.node_begin = mesh_roots[p.mesh]; d.node_end = 0;
+                d.node_begin = mesh_roots[p.mesh];
             }
         } else {
             std::memcpy(d.d, p.data, 32 * sizeof(float));
         }
     }
+    for (uint32_t i = sc->n_primitives; i-- > 0;)               // runs of one kind: the list walk loops over a run without re-dispatching on the kind
+        prims[i].run_end = (i + 1 < sc->n_primitives && prims[i + 1].kind == prims[i].kind) ? prims[i + 1].run_end : i + 1;
     int rc;
     if ((rc = ctx->prims.ensure(prims.size()))) return rc;
     if ((rc = ctx->mats.ensure(sc->n_materials))) return rc;

@@ -24,7 +24,8 @@
 namespace mi355rt {
 
 struct DevPrim {                 // 56 words = 224 B
-    uint32_t kind, material, node_begin, node_end;   // node range for MI355RT_PRIM_MESH
+    uint32_t kind, material, node_begin, run_end;    // node_begin: root node of a MI355RT_PRIM_MESH; run_end: list index one past the
+                                                     // run of consecutive primitives of this kind that this one belongs to (> own index)
     // sphere: c[3], r | plane: p1[3], n[3] | quad: base, e0, e1, n, d, inv0, inv1 (15)
     // cube / mesh: w2o[16] (column-major), o2w rows 0..2 of its 4 columns as o2w[12] = {c0.xyz, c1.xyz, c2.xyz, c3.xyz},
     //              zd[3] = w2o.w_axis.xyz * 0.0f, zn[3] = {w2o[3], w2o[7], w2o[11]} * 0.0f,

@@ -214,6 +214,12 @@ DI void set_face(Hit& h, f3 rd, f3 outward, uint32_t material) {                
 }
 
 // objects/sphere.rs:15-53 (rejections folded into one predicate; sqrt of a negative discriminant is discarded)
+// Every test below PROBES: it reads the candidate only as t_max and hands back fresh values (accepted?, t, aux); the one
+// place that changes the loop-carried candidate is cand_take()'s selects.  (A test that assigned the candidate inside its own
+// branches made the compiler carry two copies of it through the structurised switch: ~10 v_mov per quad, ~25 per cube.)
+struct Probe { float t, aux; };
+DI bool cand_take(Cand& c, bool acc, uint32_t i, float t) { c.t = acc ? t : c.t; c.idx = acc ? i : c.idx; return acc; }
+DI bool cand_take(Cand& c, bool acc, uint32_t i, const Probe& o) { c.aux = acc ? o.aux : c.aux; return cand_take(c, acc, i, o.t); }
 DI bool hit_sphere(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     f3 center = mk(pr->d[0], pr->d[1], pr->d[2]); float radius = pr->d[3];
     f3 oc = ro - center;
@@ -221,13 +227,15 @@ DI bool hit_sphere(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     float half_b = dot(oc, rd);
     float cc = dot(oc, oc) - radius * radius;
     float disc = half_b * half_b - a * cc;
-    float sqrtd = sqrtf(disc);
-    float r0 = (-half_b - sqrtd) / a, r1 = (-half_b + sqrtd) / a;
-    const float t_max = c.t;
-    const bool ok0 = !(r0 <= t_min || r0 >= t_max), ok1 = !(r1 <= t_min || r1 >= t_max);
-    if (disc < 0.0f || !(ok0 || ok1)) return false;
-    c.t = ok0 ? r0 : r1; c.idx = i;
-    return true;
+    bool acc = false; float t = 0.f;
+    if (!(disc < 0.0f)) {                                   // a wave whose lanes all miss the sphere skips the sqrt and the two divisions
+        float sqrtd = sqrtf(disc);
+        float r0 = (-half_b - sqrtd) / a, r1 = (-half_b + sqrtd) / a;
+        const float t_max = c.t;
+        const bool ok0 = !(r0 <= t_min || r0 >= t_max), ok1 = !(r1 <= t_min || r1 >= t_max);
+        acc = ok0 || ok1; t = ok0 ? r0 : r1;
+    }
+    return cand_take(c, acc, i, t);
 }
 
 // objects/plane.rs:26-56
@@ -235,9 +243,7 @@ DI bool hit_plane(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     f3 p1 = mk(pr->d[0], pr->d[1], pr->d[2]), n = mk(pr->d[3], pr->d[4], pr->d[5]);
     float denom = dot(n, rd);
     float t = dot(n, p1 - ro) / denom;
-    if ((fabsf(denom) < EPS) || (t <= t_min || t >= c.t)) return false;
-    c.t = t; c.idx = i;
-    return true;
+    return cand_take(c, !(fabsf(denom) < EPS) && !(t <= t_min || t >= c.t), i, t);
 }
 
 // tungsten/objects/quad.rs:83-132.  The two cheap rejections (parallel ray, t out of range) are folded into one
@@ -255,9 +261,7 @@ DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     float l0 = dot(v, mk(pr->d[3], pr->d[4], pr->d[5])) * pr->d[13];
     float l1 = dot(v, mk(pr->d[6], pr->d[7], pr->d[8])) * pr->d[14];
     const float lo = -EPS, hi = 1.0f + EPS;
-    const bool acc = candidate && ((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi));
-    c.t = acc ? t : c.t; c.idx = acc ? i : c.idx;
-    return acc;
+    return cand_take(c, candidate && ((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi)), i, t);
 #else
     if (!candidate) return false;
     f3 hit_pos = ro + rd * t;
@@ -315,13 +319,15 @@ DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, Cand& c)
     const float t_hit = (t_enter > 0.0f) ? t_enter : t_exit;
     const float t_max = c.t;
     const bool candidate = !(t_exit < t_enter || t_exit <= 0.0f) && !(t_hit >= t_max || t_hit <= t_min || t_hit < EPS);   // cube.rs:90-103, one branch
-    if (!candidate) return false;
-    f3 po = ro + rd * t_hit;
-    f3 pw = xform_o2w_point(pr, po);
-    const float t_world = dot(pw - ro_w, rd_w);                                             // cube.rs:145-153: the same dot product twice
-    if ((t_world < 0.0f) || (t_world < t_min || t_world > t_max)) return false;
-    c.t = t_world; c.idx = i; c.aux = t_hit;
-    return true;
+    Probe o; o.t = 0.f; o.aux = t_hit;
+    bool acc = false;
+    if (candidate) {
+        f3 po = ro + rd * t_hit;
+        f3 pw = xform_o2w_point(pr, po);
+        o.t = dot(pw - ro_w, rd_w);                                                         // cube.rs:145-153: the same dot product twice
+        acc = !((o.t < 0.0f) || (o.t < t_min || o.t > t_max));
+    }
+    return cand_take(c, acc, i, o);
 }
 // The record of a cube hit.  The object-space normal is +-e_axis, normalize_or_zero() of such a vector is the vector
 // itself (1/sqrt(1) == 1), and the world normal normalized(w2o^T * (n, 0)) therefore takes one of 6 values per cube, which
@@ -429,11 +435,11 @@ DI void mesh_leaf(const float4* __restrict__ t4, float t_min, MeshTrav& m) {
 }
 // The end of Mesh::hit that decides acceptance (mesh_object.rs:312-318); the record is built by finish_mesh() for the winner.
 DI bool mesh_accept(uint32_t i, const MeshTrav& m, f3 rd_w, float t_min, Cand& c) {
-    if (m.best_tri == 0xFFFFFFFFu) return false;
     float t_world = m.best_t * m.len_raw / len(rd_w);                   // (sic) mesh_object.rs:312-314
-    if (t_world < t_min || t_world > c.t) return false;
-    c.t = t_world; c.idx = i; c.aux = m.best_t; c.aux2 = m.best_tri;
-    return true;
+    const bool acc = (m.best_tri != 0xFFFFFFFFu) && !(t_world < t_min || t_world > c.t);
+    c.aux2 = acc ? m.best_tri : c.aux2;
+    Probe o; o.t = t_world; o.aux = m.best_t;
+    return cand_take(c, acc, i, o);
 }
 // mesh_object.rs:264-310 for the winning triangle: the object-space ray is recomputed exactly as mesh_setup() computed it.
 template <class PrimPtr>
@@ -486,15 +492,21 @@ DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__
 // hittable.rs:45-58 -- HittableList::hit with t_min = EPSILON, t_max = INFINITY (renderer.rs:24)
 template <bool HAS_MESH>
 DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro, f3 rd, Cand& c) {
-    for (uint32_t i = 0; i < n_prims; ++i) {
-        cprim_t pr = prims + i;
-        switch (pr->kind) {                               // wave-uniform: scalar branch
-            case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ro, rd, EPS, c); break;
-            case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ro, rd, EPS, c); break;
-            case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ro, rd, EPS, c); break;
-            case MI355RT_PRIM_CUBE:   hit_cube(pr, i, ro, rd, EPS, c); break;
-            default:                  if (HAS_MESH) hit_mesh(pr, i, nodes, tris, ro, rd, EPS, c); break;
-        }
+    // Same order as the list, but the dispatch on the kind (wave-uniform: a scalar branch) is taken once per RUN of equal kinds
+    // (DevPrim.run_end, host-computed) and each kind has its own tight loop: the structurised switch inside one loop carried the
+    // candidate through a chain of merge blocks with register copies at every one of them.
+    // The kinds are tried in a fixed cyclic order, each as `if (the run at i is of this kind) loop over the run`: plain nested
+    // structured control flow (a `switch` here is lowered to a chain of flow blocks, each with its own copies of the candidate).
+    uint32_t i = 0;
+    while (i < n_prims) {
+#define MI_RUN(KIND, CALL) if (i < n_prims && prims[i].kind == (KIND)) { const uint32_t end = min(prims[i].run_end, n_prims); do { CALL; } while (++i < end); }
+        MI_RUN(MI355RT_PRIM_QUAD,   hit_quad(prims + i, i, ro, rd, EPS, c))
+        MI_RUN(MI355RT_PRIM_CUBE,   hit_cube(prims + i, i, ro, rd, EPS, c))
+        MI_RUN(MI355RT_PRIM_SPHERE, hit_sphere(prims + i, i, ro, rd, EPS, c))
+        MI_RUN(MI355RT_PRIM_PLANE,  hit_plane(prims + i, i, ro, rd, EPS, c))
+        if (HAS_MESH) { MI_RUN(MI355RT_PRIM_MESH, hit_mesh(prims + i, i, nodes, tris, ro, rd, EPS, c)) }
+        else if (i < n_prims && prims[i].kind >= MI355RT_PRIM_MESH) ++i;          // cannot happen (the host picks this kernel only for mesh-free lists); keeps the loop finite
+#undef MI_RUN
     }
 }
 template <bool HAS_MESH>
@@ -572,13 +584,14 @@ DI f3 texture_lookup(const DevTexture* __restrict__ texs, uint32_t index, float 
 }
 
 template <bool SIMPLE, class Rng>
-DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted, bool& diffuse_out) {
+DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, float& side, f3& raw_d, f3& atten, f3& emitted, bool& diffuse_out) {
     const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
     const uint32_t kind = __float_as_uint(q0.x);
     const f3 albedo = mk(q0.y, q0.z, q0.w);
     const bool front_face = (h.mat_ff >> 31) != 0;
     emitted = mk(0.f, 0.f, 0.f);
     diffuse_out = false;
+    side = EPS;                                                                    // every material but the dielectric leaves on the normal's side
     if (kind == MI355RT_MAT_EMISSIVE) { emitted = albedo; return false; }         // material.rs:179-191
     if (kind == MI355RT_MAT_NULL) return false;                                   // material.rs:239-251
     rng.begin_scatter();
@@ -603,9 +616,7 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
         float cosine = (dn > 0.0f) ? ior * dn / len(rd_in) : -dn / len(rd_in);
         float reflect_prob = schlick(cosine, ior);
         if (rng.uniform01_0() < reflect_prob) {
-            f3 reflected = normalized(rd_in - (h.n * 2.0f) * dot(rd_in, h.n));     // Vec3::reflect, vec3.rs:68-70
-            new_o = h.p + h.n * EPS;
-            new_d = normalized(reflected);                                         // Ray::new
+            raw_d = rd_in - (h.n * 2.0f) * dot(rd_in, h.n);                        // Vec3::reflect, vec3.rs:68-70: .normalized(), then Ray::new
             atten = mk(0.9f, 0.9f, 0.9f);
         } else {
             diffuse = true;
@@ -620,8 +631,7 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
             fuzzed = reflected + p * fuzz;
         }
         if (!(dot(fuzzed, h.n) > 0.0f)) return false;
-        new_o = h.p + h.n * EPS;
-        new_d = normalized(normalized(fuzzed));
+        raw_d = fuzzed;
     } else if (kind == MI355RT_MAT_DIELECTRIC) {                                   // material.rs:122-162
         float ri = m4[1].w;
         float ratio = front_face ? (1.0f / ri) : (ri / 1.0f);
@@ -639,8 +649,8 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
             float par2 = 1.0f - len2(perp);
             dir = (par2 < 0.0f) ? mat_reflect(unit, h.n) : perp + h.n * (-sqrtf(par2));
         }
-        new_o = (dot(dir, h.n) > 0.0f) ? h.p + h.n * EPS : h.p - h.n * EPS;
-        new_d = normalized(normalized(dir));
+        side = (dot(dir, h.n) > 0.0f) ? EPS : -EPS;                                // p - n*EPS == p + n*(-EPS) bit for bit
+        raw_d = dir;
         atten = mk(1.f, 1.f, 1.f);
     } else {                                                                       // RoughConductor, tungsten/materials.rs:306-377
         const bool ggx = (kind == MI355RT_MAT_ROUGH_GGX);
@@ -681,28 +691,31 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
         f3 num = f * g * v_dot_h;
         float den = n_dot_v * n_dot_h + EPS;
         atten = (den > EPS) ? albedo * divf(num, den) : mk(0.f, 0.f, 0.f);
-        new_o = h.p + n * EPS;
-        new_d = normalized(normalized(l));
+        raw_d = l;
     }
     diffuse_out = diffuse;
     return true;
 }
-DI void diffuse_finish(const Hit& h, f3 p, f3& new_o, f3& new_d) {                  // material.rs:54-62
+DI f3 diffuse_finish(const Hit& h, f3 p) {                                          // material.rs:54-62
     f3 dir = h.n + normalized(p);
-    if (near_zero(dir)) dir = h.n;
-    new_o = h.p + h.n * EPS;
-    new_d = normalized(normalized(dir));                                           // .normalized() then Ray::new
+    return near_zero(dir) ? h.n : dir;
 }
+// What every scatter() and Camera::get_ray end with: `.normalized()` of the direction, then Ray::new normalises again
+// (ray.rs:12-17) -- and the origin offset along the normal.  The callers run it ONCE for all lanes of the wave, whatever
+// branch produced the raw direction (it was the tail of every material branch and of the camera ray: ~66 instructions each).
+DI f3 ray_direction(f3 raw) { return normalized(normalized(raw)); }
+DI f3 scatter_origin(const Hit& h, float side) { return h.p + h.n * side; }
 // Sequential composition (reference-stream replay kernel): random_in_unit_sphere as the plain loop, vec3.rs:54-61.
 template <class Rng>
 DI bool surface_scatter(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted) {
-    bool diffuse = false;
-    if (!scatter_pre<false>(mats, texs, q0, h, rd_in, rng, new_o, new_d, atten, emitted, diffuse)) return false;
+    bool diffuse = false; float side = EPS; f3 raw = mk(0.f, 0.f, 1.f);
+    if (!scatter_pre<false>(mats, texs, q0, h, rd_in, rng, side, raw, atten, emitted, diffuse)) return false;
     if (diffuse) {
         f3 p; uint32_t j = 0;
         do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));
-        diffuse_finish(h, p, new_o, new_d);
+        raw = diffuse_finish(h, p);
     }
+    new_o = scatter_origin(h, side); new_d = ray_direction(raw);
     return true;
 }
 
@@ -722,14 +735,16 @@ DI f3 miss_colour(const float* __restrict__ sky, uint32_t sky_w, uint32_t sky_h,
 }
 
 // camera.rs:33-42 + ray.rs:12-17
-DI void camera_ray(const DevCamera& cam, float u, float v, f3& ro, f3& rd) {
+DI f3 camera_raw(const DevCamera& cam, float u, float v) {                         // the direction before its two normalisations
     float ndc_x = 2.0f * u - 1.0f;
     float ndc_y = 1.0f - 2.0f * v;
     f3 right = mk(cam.right[0], cam.right[1], cam.right[2]), up = mk(cam.true_up[0], cam.true_up[1], cam.true_up[2]);
     f3 offset = right * (ndc_x * cam.half_width) + up * (ndc_y * cam.half_height);
-    f3 dir = normalized(mk(cam.forward[0], cam.forward[1], cam.forward[2]) + offset);
+    return mk(cam.forward[0], cam.forward[1], cam.forward[2]) + offset;
+}
+DI void camera_ray(const DevCamera& cam, float u, float v, f3& ro, f3& rd) {
     ro = mk(cam.position[0], cam.position[1], cam.position[2]);
-    rd = normalized(dir);
+    rd = ray_direction(camera_raw(cam, u, v));
 }
 
 DI uint32_t mbcnt64(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
@@ -859,12 +874,16 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 // Must be called by the whole wave in uniform control flow (it ballots): lanes that are busy elsewhere
 // pass live = false and can_take = false and are left untouched.
 // Returns false when no lane is live afterwards and no work is left to deal.
-template <bool SIMPLE>
+// DEFAULTS: give the per-lane temporaries default values.  The lockstep kernels run without (every value is read only on the
+// path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %); the register allocation of the
+// state-machine / pool / wavefront kernels is better WITH them (wavefront: 38 spilled registers with, 120 without).
+template <bool SIMPLE, bool DEFAULTS = true>
 DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
     Rad* __restrict__ radiance = reinterpret_cast<Rad*>(P.radiance);
-    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 q0;                                                                            // first 16 bytes of the hit material; read by lanes that loaded it
+    if (DEFAULTS) q0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         f3 term = mk(0.f, 0.f, 0.f); bool fin = false;
         if (!hit) { term = miss_colour(P.sky, P.sky_w, P.sky_h, P.miss, ps.rd); fin = true; }   // renderer.rs:38-63
@@ -881,36 +900,78 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
     if (wc.deal(P, can_take && !live, lane, ps.sidx)) { start_path(P, ps.sidx, ps.rng, ps.px, ps.py); fresh = true; live = true; ++n_paths; }
     if (__ballot(live) == 0ull) return !wc.exhausted();
     bool diffuse = false, scattered = false;
-    f3 no = mk(0.f, 0.f, 0.f), nd = mk(0.f, 0.f, 1.f), atten = mk(0.f, 0.f, 0.f), emitted = mk(0.f, 0.f, 0.f);
-    if (live) {
-        if (!fresh) ps.rng.next_event();
-        ps.rng.load_block0();
-        if (fresh) {
-            const float u = ((float)ps.px + ps.rng.jitter_u()) / (float)P.width;         // renderer.rs:96
-            const float v = ((float)ps.py + ps.rng.jitter_v()) / (float)P.height;        // renderer.rs:97
-            camera_ray(P.cam, u, v, ps.ro, ps.rd);                                       // renderer.rs:99
-            ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
-            if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
-        } else {
-            scattered = scatter_pre<SIMPLE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, no, nd, atten, emitted, diffuse);
+    f3 raw, atten, emitted; float side;              // written by the branch a lane takes below, read only on that lane's own path
+    if constexpr (DEFAULTS) {
+        raw = mk(0.f, 0.f, 1.f); atten = mk(0.f, 0.f, 0.f); emitted = mk(0.f, 0.f, 0.f); side = EPS;
+        if (live) {
+            if (!fresh) ps.rng.next_event();
+            ps.rng.load_block0();
+            if (fresh) {
+                const float u = ((float)ps.px + ps.rng.jitter_u()) / (float)P.width;         // renderer.rs:96
+                const float v = ((float)ps.py + ps.rng.jitter_v()) / (float)P.height;        // renderer.rs:97
+                raw = camera_raw(P.cam, u, v);                                               // renderer.rs:99; normalised below with the scattered rays
+                ps.ro = mk(P.cam.position[0], P.cam.position[1], P.cam.position[2]);
+                ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
+                if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
+            } else {
+                scattered = scatter_pre<SIMPLE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, diffuse);
+            }
         }
-    }
-    prof.mark(5);
-    const f3 ball = unit_ball_cooperative(diffuse, ps.rng, lane);                        // whole wave, uniform control flow
-    if (live && !fresh) {
-        if (scattered) {
-            if (diffuse) diffuse_finish(h, ball, no, nd);
-            ps.thr = ps.thr * atten; ps.ro = no; ps.rd = nd; ++ps.ray_index;
-            if (ps.ray_index == P.max_depth) {                                           // next level has depth == 0 (renderer.rs:20-22)
-                const f3 L = ps.thr * mk(0.f, 0.f, 0.f);
+        prof.mark(5);
+        const f3 ball = unit_ball_cooperative(diffuse, ps.rng, lane);                        // whole wave, uniform control flow
+        if (live && !fresh) {
+            if (scattered) {
+                if (diffuse) raw = diffuse_finish(h, ball);
+                ps.thr = ps.thr * atten; ps.ro = scatter_origin(h, side); ++ps.ray_index;
+                if (ps.ray_index == P.max_depth) {                                           // next level has depth == 0 (renderer.rs:20-22)
+                    const f3 L = ps.thr * mk(0.f, 0.f, 0.f);
+                    radiance[ps.sidx] = Rad{L.x, L.y, L.z}; live = false;
+                }
+            } else {                                                                         // absorbed: scatter -> None (renderer.rs:35)
+                const f3 L = ps.thr * emitted;
                 radiance[ps.sidx] = Rad{L.x, L.y, L.z}; live = false;
             }
-        } else {                                                                         // absorbed: scatter -> None (renderer.rs:35)
-            const f3 L = ps.thr * emitted;
-            radiance[ps.sidx] = Rad{L.x, L.y, L.z}; live = false;
         }
+        if (live) { ps.rd = ray_direction(raw); ++n_rays; }                                  // fresh and scattered lanes together
+    } else {
+        // Lockstep kernels: every lane of the wave passes through here in every iteration, so a lane that is not live afterwards
+        // is idle until it is dealt a fresh path (which sets all of its state) or for good -- its path state may hold anything.
+        // The branches therefore only PRODUCE the next state (fresh values, nothing carried through them) and the state is
+        // overwritten for all lanes at the end: no conditional updates of loop-carried registers, no copies to merge them.
+        f3 n_ro, n_thr; uint32_t n_ri;
+        if (!fresh) ps.rng.next_event();
+        ps.rng.load_block0();
+        if (live) {
+            if (fresh) {
+                const float u = ((float)ps.px + ps.rng.jitter_u()) / (float)P.width;         // renderer.rs:96
+                const float v = ((float)ps.py + ps.rng.jitter_v()) / (float)P.height;        // renderer.rs:97
+                raw = camera_raw(P.cam, u, v);                                               // renderer.rs:99; normalised below with the scattered rays
+                n_ro = mk(P.cam.position[0], P.cam.position[1], P.cam.position[2]);
+                n_thr = mk(1.f, 1.f, 1.f); n_ri = 0;
+                if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
+            } else {
+                scattered = scatter_pre<SIMPLE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, diffuse);
+            }
+        }
+        prof.mark(5);
+        const f3 ball = unit_ball_cooperative(diffuse, ps.rng, lane);                        // whole wave, uniform control flow
+        if (live && !fresh) {
+            if (scattered) {
+                if (diffuse) raw = diffuse_finish(h, ball);
+                n_thr = ps.thr * atten; n_ro = scatter_origin(h, side); n_ri = ps.ray_index + 1u;
+                if (n_ri == P.max_depth) {                                                   // next level has depth == 0 (renderer.rs:20-22)
+                    const f3 L = n_thr * mk(0.f, 0.f, 0.f);
+                    radiance[ps.sidx] = Rad{L.x, L.y, L.z}; live = false;
+                }
+            } else {                                                                         // absorbed: scatter -> None (renderer.rs:35)
+                const f3 L = ps.thr * emitted;
+                radiance[ps.sidx] = Rad{L.x, L.y, L.z}; live = false;
+            }
+        }
+        ps.ro = n_ro; ps.thr = n_thr; ps.ray_index = n_ri;
+        ps.rd = ray_direction(raw);                                                          // fresh and scattered lanes together
+        if (live) ++n_rays;
     }
-    if (live) ++n_rays;
     prof.mark(3);
     return true;
 }
@@ -962,11 +1023,10 @@ DI void render_ctr_lockstep(const RenderParams& P) {
     unsigned long long t_dry = 0ull; uint32_t drain_iters = 0, live_at_dry = 0;
 #endif
     for (;;) {
-        Hit h; bool hit = false;
-        h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
+        Hit h; bool hit = false;                           // h is read only where `hit` says it was written: no default values to copy around
         if (live) hit = hit_scene<HAS_MESH>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<SIMPLE>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<SIMPLE, false>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths
@@ -1882,7 +1942,7 @@ __global__ void __launch_bounds__(64) k_debug_hit(const DevPrim* prims_, uint32_
     if (i >= n) return;
     const DebugHitIn r = in[i];
     const f3 ro = mk(r.o[0], r.o[1], r.o[2]), rd = normalized(mk(r.d[0], r.d[1], r.d[2]));       // Ray::new, ray.rs:12-17
-    Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
+    Hit h;
     const bool hit = hit_scene<true>((cprim_t)prims_, n_prims, nodes, tris, ro, rd, h);
     DebugHitOut o{};
     o.hit = hit ? 1.0f : 0.0f;
