@@ -26,6 +26,7 @@
 // CPU oracle bit-for-bit wherever only + - * / sqrt are involved.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "rt_device.h"
 #include "../../../include/mi355rt.h"
 
@@ -206,6 +207,10 @@ struct Cand {
     uint32_t aux2;      // mesh: the winning triangle (index into the leaf-ordered array)
 };
 DI void cand_reset(Cand& c) { c.t = __builtin_inff(); c.idx = CAND_NONE; c.aux = 0.f; c.aux2 = 0u; }
+// The lockstep kernels of mesh-free scenes carry the cube's object-space hit point as well (3 more registers that only the cube
+// loop touches): finish_cube() then needs neither the object-space ray nor `aux` again (-42 instructions per shaded cube hit).
+struct CandP : Cand { f3 po; };
+DI void cand_reset(CandP& c) { cand_reset(static_cast<Cand&>(c)); c.po = mk(0.f, 0.f, 0.f); }
 
 DI void set_face(Hit& h, f3 rd, f3 outward, uint32_t material) {                 // hittable.rs:19-26
     bool front = dot(rd, outward) < 0.0f;
@@ -217,9 +222,13 @@ DI void set_face(Hit& h, f3 rd, f3 outward, uint32_t material) {                
 // Every test below PROBES: it reads the candidate only as t_max and hands back fresh values (accepted?, t, aux); the one
 // place that changes the loop-carried candidate is cand_take()'s selects.  (A test that assigned the candidate inside its own
 // branches made the compiler carry two copies of it through the structurised switch: ~10 v_mov per quad, ~25 per cube.)
-struct Probe { float t, aux; };
+struct Probe { float t, aux; f3 po; };
 DI bool cand_take(Cand& c, bool acc, uint32_t i, float t) { c.t = acc ? t : c.t; c.idx = acc ? i : c.idx; return acc; }
 DI bool cand_take(Cand& c, bool acc, uint32_t i, const Probe& o) { c.aux = acc ? o.aux : c.aux; return cand_take(c, acc, i, o.t); }
+DI bool cand_take(CandP& c, bool acc, uint32_t i, const Probe& o) {
+    c.po.x = acc ? o.po.x : c.po.x; c.po.y = acc ? o.po.y : c.po.y; c.po.z = acc ? o.po.z : c.po.z;
+    return cand_take(static_cast<Cand&>(c), acc, i, o.t);
+}
 DI bool hit_sphere(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     f3 center = mk(pr->d[0], pr->d[1], pr->d[2]); float radius = pr->d[3];
     f3 oc = ro - center;
@@ -307,7 +316,8 @@ DI uint32_t cube_axis(f3 po) {                                                  
     return (fabsf(ax - 0.5f) < tol) ? 0u : (fabsf(ay - 0.5f) < tol) ? 1u : (fabsf(az - 0.5f) < tol) ? 2u
          : (ax > ay && ax > az) ? 0u : (ay > az) ? 1u : 2u;
 }
-DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, Cand& c) {
+template <class C>
+DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, C& c) {
     f3 ro = xform_w2o_point(pr, ro_w);
     f3 rd = xform_w2o_dir(pr, rd_w);
     float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
@@ -323,6 +333,7 @@ DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, Cand& c)
     bool acc = false;
     if (candidate) {
         f3 po = ro + rd * t_hit;
+        o.po = po;
         f3 pw = xform_o2w_point(pr, po);
         o.t = dot(pw - ro_w, rd_w);                                                         // cube.rs:145-153: the same dot product twice
         acc = !((o.t < 0.0f) || (o.t < t_min || o.t > t_max));
@@ -333,10 +344,15 @@ DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, Cand& c)
 // itself (1/sqrt(1) == 1), and the world normal normalized(w2o^T * (n, 0)) therefore takes one of 6 values per cube, which
 // the host precomputed with the same f32 operations (DevPrim.d[34..51], rt_api.cpp cube_normal_table).
 template <class PrimPtr>
-DI void finish_cube(PrimPtr pr, const Cand& c, f3 ro_w, f3 rd_w, Hit& h) {
+DI f3 cube_po(PrimPtr pr, const Cand& c, f3 ro_w, f3 rd_w) {                                // cube.rs:104, from the slab distance the candidate kept
     const f3 ro = xform_w2o_point(pr, ro_w), rd = xform_w2o_dir(pr, rd_w);
-    const f3 po = ro + rd * c.aux;                                                          // cube.rs:104
-    h.t = c.t; h.p = xform_o2w_point(pr, po);
+    return ro + rd * c.aux;
+}
+template <class PrimPtr> DI f3 cube_po(PrimPtr, const CandP& c, f3, f3) { return c.po; }  // ... or the point itself
+template <class PrimPtr, class C>
+DI void finish_cube(PrimPtr pr, const C& c, f3 ro_w, f3 rd_w, f3& p, f3& outward) {
+    const f3 po = cube_po(pr, c, ro_w, rd_w);
+    p = xform_o2w_point(pr, po);
     const uint32_t axis = cube_axis(po);
     const float cc = (axis == 0u) ? po.x : ((axis == 1u) ? po.y : po.z);
     f3 nw;
@@ -346,7 +362,7 @@ DI void finish_cube(PrimPtr pr, const Cand& c, f3 ro_w, f3 rd_w, Hit& h) {
         const auto* t = pr->d + 34u + 3u * code;
         nw = mk(t[0], t[1], t[2]);
     }
-    set_face(h, rd_w, nw, pr->material);
+    outward = nw;
 }
 
 // mesh/mesh_object.rs:263-329 + acceleration/bvh.rs:78-170 + acceleration/aabb.rs:27-45.
@@ -443,15 +459,15 @@ DI bool mesh_accept(uint32_t i, const MeshTrav& m, f3 rd_w, float t_min, Cand& c
 }
 // mesh_object.rs:264-310 for the winning triangle: the object-space ray is recomputed exactly as mesh_setup() computed it.
 template <class PrimPtr>
-DI void finish_mesh(PrimPtr pr, const float4* __restrict__ t4, const Cand& c, f3 ro_w, f3 rd_w, Hit& h) {
+DI void finish_mesh(PrimPtr pr, const float4* __restrict__ t4, const Cand& c, f3 ro_w, f3 rd_w, f3& p, f3& outward) {
     const f3 ro = xform_w2o_point(pr, ro_w);
     const f3 rd = normalized(normalized(xform_w2o_dir(pr, rd_w)));
     const float4 r2 = t4[3 * (size_t)c.aux2 + 2];
     f3 tn = mk(r2.y, r2.z, r2.w);
     f3 pos_obj = ro + rd * c.aux;
     f3 n_obj = (dot(rd, tn) < 0.0f) ? tn : -tn;                         // bvh.rs:118-124
-    h.t = c.t; h.p = xform_o2w_point(pr, pos_obj);
-    set_face(h, rd_w, normalized(xform_normal(pr, n_obj)), pr->material);
+    p = xform_o2w_point(pr, pos_obj);
+    outward = normalized(xform_normal(pr, n_obj));
 }
 DI bool hit_mesh(cprim_t pr, uint32_t i, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro_w, f3 rd_w,
                  float t_min, Cand& c) {
@@ -467,31 +483,55 @@ DI bool hit_mesh(cprim_t pr, uint32_t i, const DevNode* __restrict__ nodes, cons
 
 // The HitRecord of the list's winner (hittable.rs:10-27), once per ray.  Lanes of a wave may have different winners, so
 // the primitive record is read per lane here (global loads; L1/L2 resident).
-template <bool HAS_MESH>
-DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__ tris, const Cand& c, f3 ro, f3 rd, Hit& h) {
+template <bool HAS_MESH, class C>
+DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__ tris, const C& c, f3 ro, f3 rd, Hit& h) {
     const DevPrim* __restrict__ pr = prims + c.idx;
     const uint32_t kind = pr->kind;
-    if (kind == MI355RT_PRIM_QUAD) {                                      // quad.rs:103-131
-        const f3 n = mk(pr->d[9], pr->d[10], pr->d[11]);
-        h.t = c.t; h.p = ro + rd * c.t;
-        set_face(h, rd, n, pr->material);                                 // dot(ray.direction, normal): the same sum of the same products as `denom`
-    } else if (kind == MI355RT_PRIM_CUBE) {
-        finish_cube(pr, c, ro, rd, h);
-    } else if (kind == MI355RT_PRIM_SPHERE) {                             // sphere.rs:35-52
-        const f3 center = mk(pr->d[0], pr->d[1], pr->d[2]); const float radius = pr->d[3];
-        h.t = c.t; h.p = ro + rd * c.t;
-        set_face(h, rd, divf(h.p - center, radius), pr->material);
-    } else if (kind == MI355RT_PRIM_PLANE) {                              // plane.rs:40-55
-        h.t = c.t; h.p = ro + rd * c.t;
-        set_face(h, rd, mk(pr->d[3], pr->d[4], pr->d[5]), pr->material);
-    } else if (HAS_MESH) {
-        finish_mesh(pr, reinterpret_cast<const float4*>(tris), c, ro, rd, h);
+    // Mesh-free lists: each kind only says where the hit is and which way its surface faces; HitRecord::set_face_normal
+    // (hittable.rs:19-26) then runs once for all lanes of the wave, whatever their winners are (cornell -2.5 %).  With meshes in
+    // the list every kind finishes its own record (measured: the shared tail costs the wavefront kernel 3-4 %).
+#ifndef MI355RT_FINISH_SHARED
+#define MI355RT_FINISH_SHARED (!HAS_MESH)
+#endif
+    if (MI355RT_FINISH_SHARED) {
+        f3 p = ro + rd * c.t, outward;                                        // sphere.rs:35, plane.rs:40, quad.rs:103
+        if (kind == MI355RT_PRIM_QUAD) {                                      // quad.rs:103-131
+            outward = mk(pr->d[9], pr->d[10], pr->d[11]);                     // dot(ray.direction, normal): the same sum of the same products as `denom`
+        } else if (kind == MI355RT_PRIM_CUBE) {
+            finish_cube(pr, c, ro, rd, p, outward);
+        } else if (kind == MI355RT_PRIM_SPHERE) {                             // sphere.rs:35-52
+            outward = divf(p - mk(pr->d[0], pr->d[1], pr->d[2]), pr->d[3]);
+        } else if (kind == MI355RT_PRIM_PLANE) {                              // plane.rs:40-55
+            outward = mk(pr->d[3], pr->d[4], pr->d[5]);
+        } else if (HAS_MESH) {
+            finish_mesh(pr, reinterpret_cast<const float4*>(tris), c, ro, rd, p, outward);
+        }
+        h.t = c.t; h.p = p;
+        set_face(h, rd, outward, pr->material);
+    } else {
+        h.t = c.t;
+        if (kind == MI355RT_PRIM_QUAD) {
+            h.p = ro + rd * c.t;
+            set_face(h, rd, mk(pr->d[9], pr->d[10], pr->d[11]), pr->material);
+        } else if (kind == MI355RT_PRIM_CUBE) {
+            f3 outward; finish_cube(pr, c, ro, rd, h.p, outward);
+            set_face(h, rd, outward, pr->material);
+        } else if (kind == MI355RT_PRIM_SPHERE) {
+            h.p = ro + rd * c.t;
+            set_face(h, rd, divf(h.p - mk(pr->d[0], pr->d[1], pr->d[2]), pr->d[3]), pr->material);
+        } else if (kind == MI355RT_PRIM_PLANE) {
+            h.p = ro + rd * c.t;
+            set_face(h, rd, mk(pr->d[3], pr->d[4], pr->d[5]), pr->material);
+        } else if (HAS_MESH) {
+            f3 outward; finish_mesh(pr, reinterpret_cast<const float4*>(tris), c, ro, rd, h.p, outward);
+            set_face(h, rd, outward, pr->material);
+        }
     }
 }
 
 // hittable.rs:45-58 -- HittableList::hit with t_min = EPSILON, t_max = INFINITY (renderer.rs:24)
-template <bool HAS_MESH>
-DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro, f3 rd, Cand& c) {
+template <bool HAS_MESH, class C>
+DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro, f3 rd, C& c) {
     // Same order as the list, but the dispatch on the kind (wave-uniform: a scalar branch) is taken once per RUN of equal kinds
     // (DevPrim.run_end, host-computed) and each kind has its own tight loop: the structurised switch inside one loop carried the
     // candidate through a chain of merge blocks with register copies at every one of them.
@@ -509,10 +549,12 @@ DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
 #undef MI_RUN
     }
 }
-template <bool HAS_MESH>
+// CARRY_PO: the candidate keeps the cube's object-space hit point (CandP).  On for the kernel of Lambert-only scenes (cornell
+// -1.8 %); the general mesh-free kernel has no registers to spare for it (veach-mis +1.9 % with it: spills).
+template <bool HAS_MESH, bool CARRY_PO = false>
 DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris,
                   f3 ro, f3 rd, Hit& best) {
-    Cand c; cand_reset(c);
+    typename std::conditional<CARRY_PO && !HAS_MESH, CandP, Cand>::type c; cand_reset(c);
     walk_list<HAS_MESH>(prims, n_prims, nodes, tris, ro, rd, c);
     if (c.idx == CAND_NONE) return false;
     finish_hit<HAS_MESH>((const DevPrim*)prims, tris, c, ro, rd, best);
@@ -1024,7 +1066,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
 #endif
     for (;;) {
         Hit h; bool hit = false;                           // h is read only where `hit` says it was written: no default values to copy around
-        if (live) hit = hit_scene<HAS_MESH>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
+        if (live) hit = hit_scene<HAS_MESH, SIMPLE>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
         if (!shade_and_regenerate<SIMPLE, false>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
