@@ -110,12 +110,22 @@ DI float u32_to_f01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f);
 DI float u32_to_range11(uint32_t w) { float v12 = __uint_as_float((w >> 9) | 0x3F800000u); float v01 = v12 - 1.0f; return v01 * 2.0f + -1.0f; }
 
 // Philox4x32-10: counter-based, no state.  10 x (2 x 32x32->64 multiplies + 4 xor + 2 add).
+// WIDE: one 64-bit product per multiplier -- v_mad_u64_u32 issues like ONE v_mul_hi_u32 (2.1 add slots, tools/microbench/int_mul.hip)
+// and yields both halves, where __umulhi() and `*` written separately compile to two such instructions: 20 instead of 40
+// slow multiplies per call.  The VALU-bound lockstep kernels use it (cornell -6.1 %, veach-mis -2.4 %); the latency-bound
+// wavefront kernel is 2-3 % faster on the two independent multiplies (measured), so it keeps them.  Same bits either way.
+template <bool WIDE = false>
 DI void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t hi0, lo0, hi1, lo1;
+        if (WIDE) {
+            const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+            hi0 = (uint32_t)(p0 >> 32); lo0 = (uint32_t)p0; hi1 = (uint32_t)(p1 >> 32); lo1 = (uint32_t)p1;
+        } else {
+            hi0 = __umulhi(M0, c0); lo0 = M0 * c0; hi1 = __umulhi(M1, c2); lo1 = M1 * c2;
+        }
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += W0; k1 += W1;
@@ -133,15 +143,15 @@ struct RngCtr {
     // jitter from (ray 0, block 0); a continuing path reads its scatter draws from (ray r+1, block 0).
     DI void start(uint32_t k0_, uint32_t k1_, uint32_t x_, uint32_t s_) { k0 = k0_; k1 = k1_; x = x_; s = s_; ray = 0; }
     DI void next_event() { ++ray; }
-    DI void load_block0() { philox4x32_10(k0, k1, x, s, ray, 0u, b0); }
+    template <bool WIDE = false> DI void load_block0() { philox4x32_10<WIDE>(k0, k1, x, s, ray, 0u, b0); }
     DI float jitter_u() { return u32_to_f01(b0[0]); }
     DI float jitter_v() { return u32_to_f01(b0[1]); }
     DI void begin_scatter() {}
     DI float uniform01_0() { return u32_to_f01(b0[0]); }
     DI float uniform01_1() { return u32_to_f01(b0[1]); }
-    DI f3 cube_point(uint32_t j) {
+    template <bool WIDE = false> DI f3 cube_point(uint32_t j) {
         if (j == 0) return mk(u32_to_range11(b0[1]), u32_to_range11(b0[2]), u32_to_range11(b0[3]));
-        uint32_t b[4]; philox4x32_10(k0, k1, x, s, ray, j, b);
+        uint32_t b[4]; philox4x32_10<WIDE>(k0, k1, x, s, ray, j, b);
         return mk(u32_to_range11(b[1]), u32_to_range11(b[2]), u32_to_range11(b[3]));
     }
 };
@@ -187,7 +197,7 @@ struct RngRef {
     DI void begin_scatter() {}
     DI float uniform01_0() { return u32_to_f01(next_u32()); }
     DI float uniform01_1() { return u32_to_f01(next_u32()); }
-    DI f3 cube_point(uint32_t) { float x = u32_to_range11(next_u32()); float y = u32_to_range11(next_u32()); float z = u32_to_range11(next_u32()); return mk(x, y, z); }
+    template <bool WIDE = false> DI f3 cube_point(uint32_t) { float x = u32_to_range11(next_u32()); float y = u32_to_range11(next_u32()); float z = u32_to_range11(next_u32()); return mk(x, y, z); }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -625,7 +635,7 @@ DI f3 texture_lookup(const DevTexture* __restrict__ texs, uint32_t index, float 
     return mk((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);   // :237-241
 }
 
-template <bool SIMPLE, class Rng>
+template <bool SIMPLE, bool WIDE = false, class Rng>
 DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, float& side, f3& raw_d, f3& atten, f3& emitted, bool& diffuse_out) {
     const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
     const uint32_t kind = __float_as_uint(q0.x);
@@ -669,7 +679,7 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
         f3 fuzzed = reflected;
         if (fuzz > 0.0f) {
             f3 p; uint32_t j = 0;
-            do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));          // vec3.rs:54-61
+            do { p = rng.template cube_point<WIDE>(j); ++j; } while (!(len2(p) < 1.0f));   // vec3.rs:54-61
             fuzzed = reflected + p * fuzz;
         }
         if (!(dot(fuzzed, h.n) > 0.0f)) return false;
@@ -876,6 +886,7 @@ struct PathState {
 // Must be called in wave-uniform control flow.
 DI int lane_shfl(int v, uint32_t src_lane) { return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), v); }
 DI float lane_shfl(float v, uint32_t src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v))); }
+template <bool WIDE = false>
 DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
     f3 p = mk(u32_to_range11(rng.b0[1]), u32_to_range11(rng.b0[2]), u32_to_range11(rng.b0[3]));   // try 0
     bool need = diffuse && !(len2(p) < 1.0f);
@@ -895,7 +906,7 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
         const uint32_t ox = (uint32_t)lane_shfl((int)rng.x, olane), os = (uint32_t)lane_shfl((int)rng.s, olane);
         const uint32_t oray = (uint32_t)lane_shfl((int)rng.ray, olane), oj = (uint32_t)lane_shfl((int)jbase, olane);
         uint32_t w[4];
-        philox4x32_10(ok0, ok1, ox, os, oray, oj + (lane & ((1u << lg) - 1u)), w);
+        philox4x32_10<WIDE>(ok0, ok1, ox, os, oray, oj + (lane & ((1u << lg) - 1u)), w);
         const f3 q = mk(u32_to_range11(w[1]), u32_to_range11(w[2]), u32_to_range11(w[3]));
         const uint64_t acc = __ballot(worker && (len2(q) < 1.0f));
         const uint32_t seg_lo = r << lg;                                           // my segment of the ballot (owners only)
@@ -982,7 +993,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
         // overwritten for all lanes at the end: no conditional updates of loop-carried registers, no copies to merge them.
         f3 n_ro, n_thr; uint32_t n_ri;
         if (!fresh) ps.rng.next_event();
-        ps.rng.load_block0();
+        ps.rng.load_block0<true>();
         if (live) {
             if (fresh) {
                 const float u = ((float)ps.px + ps.rng.jitter_u()) / (float)P.width;         // renderer.rs:96
@@ -992,11 +1003,11 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
                 n_thr = mk(1.f, 1.f, 1.f); n_ri = 0;
                 if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
             } else {
-                scattered = scatter_pre<SIMPLE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, diffuse);
+                scattered = scatter_pre<SIMPLE, true>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, diffuse);
             }
         }
         prof.mark(5);
-        const f3 ball = unit_ball_cooperative(diffuse, ps.rng, lane);                        // whole wave, uniform control flow
+        const f3 ball = unit_ball_cooperative<true>(diffuse, ps.rng, lane);                        // whole wave, uniform control flow
         if (live && !fresh) {
             if (scattered) {
                 if (diffuse) raw = diffuse_finish(h, ball);
