@@ -240,7 +240,7 @@ def main():
         khash = build.kernel_hash()
         pmc, pmc_state = load_pmc(args.workload, khash)
         peak_inst = VALU_SIMDS * VALU_CLOCK_HZ / VALU_CYCLES_PER_WAVE64_INST
-        achieved = frac = lane_util = traffic = None
+        achieved = frac = lane_util = traffic = insts = None
         hbm = None
         if pmc and render_ms_per_step > 0:
             insts = pmc["valu_wave_insts_per_step"] * share
@@ -265,6 +265,8 @@ def main():
                          "achieved": None if achieved is None else round(achieved / 1e9, 1), "peak": round(peak_inst / 1e9, 1),
                          "unit": "G wave-instructions/s", "frac": None if frac is None else round(frac, 4), "traffic": traffic,
                          "lane_utilisation": lane_util,
+                         "wave_insts_per_step": None if achieved is None else int(insts),
+                         "wave_insts_per_ray": None if achieved is None or st.rays == 0 else round(insts * 64.0 / st.rays, 1),   # VALU instructions a wave issues per 64 rays
                          "useful_frac": None if frac is None or lane_util is None else round(frac * lane_util, 4),
                          "hbm": hbm,
                          "kernel_ms_per_step": round(render_ms_per_step, 4), "resolve_ms_per_step": round(resolve_ms_per_step, 4),

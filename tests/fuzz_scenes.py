@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 
-def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60, only_kinds=None):
+def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60, only_kinds=None, lambert_only=False):
     from oracle import scene_loader as L
     rng = np.random.default_rng(seed)
     F = np.float32
@@ -22,6 +22,9 @@ def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60, only_kin
              mat(abi.MAT_METAL, col(), p0=0.0), mat(abi.MAT_METAL, col(), p0=rng.uniform(0.05, 0.6)),
              mat(abi.MAT_DIELECTRIC, p0=rng.uniform(1.2, 1.9)), mat(abi.MAT_EMISSIVE, tuple(rng.uniform(1, 6, 3))),
              mat(abi.MAT_PLASTIC, col(), p0=rng.uniform(1.2, 1.8)), mat(abi.MAT_NULL), mat(abi.MAT_LAMBERT_SOLID, col())]
+    if lambert_only:                                                 # what the Lambert-only lockstep kernel (k_render_ctr_simple) is picked for:
+        del mats[:]                                                  # the materials ARRAY holds nothing but Lambert (solid) / Emissive / Null
+        kinds = [mat(abi.MAT_LAMBERT_SOLID, col()), mat(abi.MAT_EMISSIVE, tuple(rng.uniform(1, 6, 3))), mat(abi.MAT_NULL), mat(abi.MAT_LAMBERT_SOLID, col())]
     if not exact_only:
         cu = ((0.2, 1.09, 1.42), (3.91, 2.57, 2.30))
         kinds += [mat(abi.MAT_ROUGH_GGX, col(), p0=rng.uniform(0.02, 0.5), eta=cu[0], k=cu[1]),

@@ -69,3 +69,33 @@ def test_state_machine_corner_shapes(label, kw, native, oracle_mod, abi):
         op, ol, cnt = oracle_mod.render(sc, sc.camera, st, opt)
         assert stats.rays == cnt.rays, label
         assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op), label
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,kw,kernel", [
+    ("every mesh-free kind, every exact material", dict(n_prims=16, only_kinds=[2, 2, 3, 0, 1, 3, 3, 0, 0, 2, 1, 1]), 0),
+    ("alternating kinds (runs of one)", dict(n_prims=12, only_kinds=[3, 2, 0, 1]), 0),
+    ("one long run", dict(n_prims=40, only_kinds=[2]), 0),
+    ("Lambert-only list", dict(n_prims=14, only_kinds=[2, 2, 2, 3, 3, 2, 0, 1, 3], lambert_only=True), 3),
+    ("Lambert-only cubes", dict(n_prims=9, only_kinds=[3], lambert_only=True), 3),
+])
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_lockstep_kernels_on_mesh_free_fuzz_scenes(label, kw, kernel, seed, native, oracle_mod, abi):
+    """Mesh-free lists go to the lockstep kernels, whose list walk loops over RUNS of equal kinds (DevPrim.run_end) and, in the
+    Lambert-only kernel, carries the cube's object-space hit point in the candidate: random lists with runs of every length and
+    order, both RNG modes, must match the oracle bit for bit -- and must really have run on the kernel the case is meant for."""
+    host, device = native
+    sc = random_scene(abi, host, seed, exact_only=True, **kw)
+    st = abi.Settings(56, 40, 5, 9)
+    ctx = device.Context(0)
+    try:
+        ctx.set_scene(sc, sc.camera, st)
+        assert ctx.kernel_variant() == kernel, label
+    finally:
+        ctx.close()
+    for mode in (0, 1):
+        opt = abi.Options.make(rng_mode=mode, seed=seed * 104729 if mode == 0 else 0)
+        gp, gl, stats = device.render(sc, sc.camera, st, opt)
+        op, ol, cnt = oracle_mod.render(sc, sc.camera, st, opt)
+        assert stats.rays == cnt.rays, label
+        assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op), label

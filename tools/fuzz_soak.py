@@ -12,7 +12,9 @@ oracle.build()
 first, n = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0; t0 = time.time()
 for seed in range(first, first + n):
-    shapes = [dict(), dict(n_prims=5, mesh_tris=400), dict(n_prims=30, mesh_tris=10), dict(n_prims=8, only_kinds=[4, 3, 4, 2], mesh_tris=150)]
+    shapes = [dict(), dict(n_prims=5, mesh_tris=400), dict(n_prims=30, mesh_tris=10), dict(n_prims=8, only_kinds=[4, 3, 4, 2], mesh_tris=150),
+              dict(n_prims=5 + seed % 19, only_kinds=[[2, 2, 3, 0, 1, 3, 3, 0, 0, 2, 1, 1], [3, 2, 0, 1], [0, 0, 3], [2, 3, 3, 1]][seed // 6 % 4]),   # mesh-free: general lockstep kernel
+              dict(n_prims=4 + seed % 13, only_kinds=[[2, 2, 2, 3, 3, 2, 0, 1, 3], [3], [2, 3]][seed // 6 % 3], lambert_only=True)]          # Lambert-only lockstep kernel
     kw = shapes[seed % len(shapes)]
     sc = random_scene(abi, host, seed, exact_only=True, **kw)
     st = abi.Settings(40 + seed % 37, 30 + seed % 23, 3 + seed % 6, 2 + seed % 11)
