@@ -1532,10 +1532,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr
 //
 // The state machine and the pool kernel keep a path in the registers of ONE lane for its whole life, so every pass of every
 // stage runs with whatever lanes of that wave happen to be in that stage (measured: 0.40 of the lanes on semesterbild).  Here
-// the CU's workgroup owns WF_PATHS path slots in LDS (36 dwords each) and five queues of slot numbers -- FREE, TOP0 (a ray at
-// the head of the list), WALK (a BVH walk in progress), TOP1 (a ray whose walk is back), SHADE.  Every wave loops: look at
-// the queue lengths, pop up to 64 slots of the fullest stage, load what that stage needs, run the stage with (nearly) all
-// lanes busy, store what changed, push each slot to the queue of its next stage.  A path therefore migrates between waves;
+// the CU's workgroup owns WF_PATHS path slots in LDS (20 dwords each) and queues of slot numbers -- FREE, WALK (a BVH walk in
+// progress), TOP1 (a ray whose walk is back), SHADE x 4 material classes.  Every wave loops: look at the queue lengths, choose a
+// stage, pop up to 64 of its slots, load what that stage needs, run the stage with (nearly) all lanes busy, store what changed,
+// push each slot to the queue of its next stage.  (A new ray has no queue of its own: the SHADE pass that generates it walks the
+// head of the list for it right away.)  A path therefore migrates between waves;
 // per path the arithmetic is exactly that of the other kernels (same device functions, same inputs, same order), so images
 // are bit-identical.  Regeneration stays in SHADE: a finished path's slot is refilled from the wave's own work cursor in the
 // same pass, and SHADE passes top themselves up from the FREE queue.
@@ -1551,17 +1552,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr
 // 832 slots each 10.65 / 6.65;  3 x 8 waves, 512 each 11.33 / 6.86;  2 x 14 at 72 VGPRs 14.8 / 9.8 and 2 x 16 at 64 VGPRs
 // 15.3 / 9.0 (spills);  2 x 10 at 96 VGPRs 15.2 / 9.7;  1 x 16 waves with 960 fat slots (36 dwords) 11.6 / 7.3.
 #ifndef MI355RT_WF_PATHS
-#define MI355RT_WF_PATHS 768
+#define MI355RT_WF_PATHS 832                                // what fits beside seven rings (768 beside the eight there were: semesterbild +2.4 %, teapot +1.6 %)
 #endif
 #ifndef MI355RT_WF_RING
 #define MI355RT_WF_RING 1024
 #endif
-constexpr uint32_t WF_PATHS = MI355RT_WF_PATHS, WF_SLOT_WORDS = 20, WF_RING = MI355RT_WF_RING, WF_QUEUES = 8, WF_CTRL_WORDS = 32;
+constexpr uint32_t WF_PATHS = MI355RT_WF_PATHS, WF_SLOT_WORDS = 20, WF_RING = MI355RT_WF_RING, WF_QUEUES = 7, WF_CTRL_WORDS = 32;
 constexpr uint32_t WF_EMPTY = 0xFFFFu, WF_WALK_DONE = 0x80000000u;
 // SHADE is four queues, one per material class of the hit: a pass whose slots all take the same branch of Material::scatter pays
 // for that branch only (a mixed pass pays for the sum of all branches that any of its lanes takes).
-enum : uint32_t { WQ_FREE = 0, WQ_TOP0 = 1, WQ_WALK = 2, WQ_TOP1 = 3,
-                  WQ_SHADE = 4,      // + class: 0 terminal (miss / emissive / null: the path ends, the slot regenerates), 1 diffuse (Lambert,
+enum : uint32_t { WQ_FREE = 0, WQ_WALK = 1, WQ_TOP1 = 2,
+                  WQ_SHADE = 3,      // + class: 0 terminal (miss / emissive / null: the path ends, the slot regenerates), 1 diffuse (Lambert,
                                      //          checker, texture, plastic), 2 rough conductor, 3 specular (metal, dielectric)
                   WQ_NONE = 15 };
 DI uint32_t shade_class(uint32_t kind) {
@@ -1660,15 +1661,59 @@ DI void render_ctr_wavefront(const RenderParams& P) {
     Prof prof; prof.begin();
     bool failed = false;
 #ifdef MI355RT_STAMPS
-    unsigned long long w_exec[4] = {0, 0, 0, 0}, w_lanes[4] = {0, 0, 0, 0};    // passes and slots per pass: 0 WALK, 1 TOP1, 2 TOP0, 3 SHADE (+ free fill)
+    unsigned long long w_exec[4] = {0, 0, 0, 0}, w_lanes[4] = {0, 0, 0, 0};    // passes and slots per pass: 0 WALK, 1 TOP1, 2 (unused: there was a TOP0 stage), 3 SHADE (+ free fill)
 #define MI355RT_WFCOUNT(i, n) do { w_exec[i] += 1; w_lanes[i] += (n); } while (0)
 #else
 #define MI355RT_WFCOUNT(i, n) do {} while (0)
 #endif
+    // TOP: hittable.rs:45-58 from the slot's cursor; a mesh whose root box is hit sends the ray to WALK; at the end of the list the
+    // slot is routed by the material class of its hit, so that SHADE passes are homogeneous.  Run by SHADE passes on the rays they
+    // have just generated (still in registers) and by TOP1 passes on the slots whose walk is back.
+    auto run_top = [&](const bool have, const f3 ro, const f3 rd, Cand c, uint32_t cursor, bool walk_done, uint32_t* sl, const uint32_t id) {
+        bool to_walk = false;
+        for (uint32_t i = 0; i < P.n_prims; ++i) {
+            const bool mine = have && !to_walk && cursor == i;
+            if (__ballot(mine) == 0ull) continue;
+            cprim_t pr = prims + i;
+            if (mine) {
+                bool advance = true;
+                switch (pr->kind) {                                       // wave-uniform: scalar branch
+                    case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_CUBE:   hit_cube(pr, i, ro, rd, EPS, c); break;
+                    default:
+                        if (!walk_done) {
+                            MeshTrav mt; mesh_setup(pr, ro, rd, c.t, mt);
+                            const uint32_t root = mt.node;
+                            mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);       // the root box, here: most rays miss it
+                            if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
+                            else {
+                                reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(root), c.t, __uint_as_float(0xFFFFFFFFu), 0.f);
+                                to_walk = true; advance = false;
+                            }
+                        } else {
+                            const float4 w = reinterpret_cast<const float4*>(sl)[4];
+                            MeshTrav mt; mt.best_t = w.y; mt.best_tri = __float_as_uint(w.z); mt.len_raw = len(xform_w2o_dir(pr, rd));   // mesh_object.rs:288, again
+                            mesh_accept(i, mt, rd, EPS, c); walk_done = false;
+                        }
+                        break;
+                }
+                if (advance) ++cursor;
+            }
+        }
+        if (have) {
+            reinterpret_cast<float4*>(sl)[3] = make_float4(c.t, __uint_as_float(c.idx), c.aux, __uint_as_float(c.aux2));
+            sl[11] = cursor;
+        }
+        uint32_t cls = 0u;
+        if (have && !to_walk && c.idx != CAND_NONE) cls = shade_class(P.mats[P.prims[c.idx].material].kind);
+        Q.push_each(have, to_walk ? (uint32_t)WQ_WALK : WQ_SHADE + cls, id, lane, failed);
+    };
     for (;;) {
         if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[17], 1u); break; }
         if (__hip_atomic_load(&Q.ctrl[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
-        const uint32_t cT1 = Q.count(WQ_TOP1), cW = Q.count(WQ_WALK), cT0 = Q.count(WQ_TOP0);
+        const uint32_t cT1 = Q.count(WQ_TOP1), cW = Q.count(WQ_WALK);
         const uint32_t cS0 = Q.count(WQ_SHADE), cS1 = Q.count(WQ_SHADE + 1u), cS2 = Q.count(WQ_SHADE + 2u), cS3 = Q.count(WQ_SHADE + 3u);
         const uint32_t cS = cS0 + cS1 + cS2 + cS3;
         const uint32_t cF = wc.exhausted() ? 0u : Q.count(WQ_FREE);
@@ -1687,9 +1732,13 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 const uint32_t w = price * (64u - min(n, 64u));
                 if (w <= waste) { waste = w; stage = q; best = n; }
             };
-            consider(WQ_TOP0, cT0, 7u); consider(WQ_WALK, cW, 11u); consider(WQ_TOP1, cT1, 4u);
-            consider(WQ_SHADE + 3u, cS3, 5u); consider(WQ_SHADE + 2u, cS2, 10u); consider(WQ_SHADE + 1u, cS1, 8u);
-            consider(WQ_SHADE, cS0 + cF, 5u);                           // terminal class: free slots ride along (both only regenerate)
+            consider(WQ_WALK, cW, 11u); consider(WQ_TOP1, cT1, 4u);
+#ifndef MI355RT_WF_T0PRICE
+#define MI355RT_WF_T0PRICE 7
+#endif
+            constexpr uint32_t T0 = MI355RT_WF_T0PRICE;                  // a SHADE pass goes on with the head of the list for the rays it generates
+            consider(WQ_SHADE + 3u, cS3, 5u + T0); consider(WQ_SHADE + 2u, cS2, 10u + T0); consider(WQ_SHADE + 1u, cS1, 8u + T0);
+            consider(WQ_SHADE, cS0 + cF, 5u + T0);                      // terminal class: free slots ride along (both only regenerate)
         }
         if (stage == WQ_NONE) {
             if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
@@ -1709,7 +1758,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #endif
         if (best < MI355RT_WF_MINFILL && naps < MI355RT_WF_PATIENCE) {
             const uint32_t alive = __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (alive > cS + cT1 + cW + cT0) { ++naps; __builtin_amdgcn_s_sleep(4); continue; }
+            if (alive > cS + cT1 + cW) { ++naps; __builtin_amdgcn_s_sleep(4); continue; }
         }
         naps = 0;
 #ifndef MI355RT_WF_KEEP
@@ -1754,9 +1803,14 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             }
             const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
             if (lane == 0 && born != died) atomicAdd(&Q.ctrl[16], (uint32_t)(born - died));
-            Q.push(WQ_TOP0, (have || fill) && live, id, lane, failed);
             Q.push(WQ_FREE, (have || fill) && !live, id, lane, failed);
+            // Every ray SHADE produces -- continuing or freshly generated -- starts at the head of the list, so the pass goes straight
+            // on with TOP for its live lanes: as homogeneous as a pass over a queue of such rays and at least as full, minus one queue
+            // round trip per ray (there was a TOP0 queue: semesterbild 9.73 -> 9.08 ms, teapot 6.49 -> 6.17 ms at 64 spp without it).
             prof.mark(4);
+            {   Cand c0; cand_reset(c0);
+                run_top((have || fill) && live, ps.ro, ps.rd, c0, 0u, false, sl, id); }
+            prof.mark(1);
             continue;
         }
 
@@ -1795,22 +1849,24 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(m.node), m.best_t, __uint_as_float(m.best_tri), 0.f);
                 if (done) sl[11] = cursor_word | WF_WALK_DONE;
             }
-            Q.push(WQ_TOP1, done, id, lane, failed);
             Q.push(WQ_WALK, have && !done, id, lane, failed);
             prof.mark(0);
+            // (Letting the finished walks go on with the rest of the list in this pass -- the WALK -> TOP1 counterpart of the fused
+            // SHADE -> TOP0 -- was measured at thresholds of 1 / 24 / 40 finished lanes: +-0.5 %, not kept.)
+            Q.push(WQ_TOP1, done, id, lane, failed);
             continue;
         }
 
         {
-            // ---- TOP0 / TOP1: hittable.rs:45-58 from the slot's cursor; a mesh whose root box is hit sends the ray to WALK ----
-            const uint32_t n = Q.pop(stage, 64u, keep(min(stage == WQ_TOP1 ? cT1 : cT0, 64u)), lane, 0u, id, failed);
+            // ---- TOP1: hittable.rs:45-58 goes on from the slot's cursor (the mesh whose walk is back) ----
+            const uint32_t n = Q.pop(WQ_TOP1, 64u, keep(min(cT1, 64u)), lane, 0u, id, failed);
             if (n == 0u) continue;
             const bool have = lane < n;
-            MI355RT_WFCOUNT(stage == WQ_TOP1 ? 1 : 2, n);
+            MI355RT_WFCOUNT(1, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
             f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
             Cand c; cand_reset(c);
-            uint32_t cursor = 0xFFFFFFFFu; bool walk_done = false, to_walk = false;
+            uint32_t cursor = 0xFFFFFFFFu; bool walk_done = false;
             if (have) {
                 const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1], g = reinterpret_cast<const float4*>(sl)[3];
                 ro = mk(a.x, a.y, a.z); rd = mk(b.x, b.y, b.z);
@@ -1818,45 +1874,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 const uint32_t cw = sl[11];
                 cursor = cw & ~WF_WALK_DONE; walk_done = (cw & WF_WALK_DONE) != 0u;
             }
-            for (uint32_t i = 0; i < P.n_prims; ++i) {
-                const bool mine = have && !to_walk && cursor == i;
-                if (__ballot(mine) == 0ull) continue;
-                cprim_t pr = prims + i;
-                if (mine) {
-                    bool advance = true;
-                    switch (pr->kind) {                                       // wave-uniform: scalar branch
-                        case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ro, rd, EPS, c); break;
-                        case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ro, rd, EPS, c); break;
-                        case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ro, rd, EPS, c); break;
-                        case MI355RT_PRIM_CUBE:   hit_cube(pr, i, ro, rd, EPS, c); break;
-                        default:
-                            if (!walk_done) {
-                                MeshTrav mt; mesh_setup(pr, ro, rd, c.t, mt);
-                                const uint32_t root = mt.node;
-                                mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);       // the root box, here: most rays miss it
-                                if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
-                                else {
-                                    reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(root), c.t, __uint_as_float(0xFFFFFFFFu), 0.f);
-                                    to_walk = true; advance = false;
-                                }
-                            } else {
-                                const float4 w = reinterpret_cast<const float4*>(sl)[4];
-                                MeshTrav mt; mt.best_t = w.y; mt.best_tri = __float_as_uint(w.z); mt.len_raw = len(xform_w2o_dir(pr, rd));   // mesh_object.rs:288, again
-                                mesh_accept(i, mt, rd, EPS, c); walk_done = false;
-                            }
-                            break;
-                    }
-                    if (advance) ++cursor;
-                }
-            }
-            if (have) {
-                reinterpret_cast<float4*>(sl)[3] = make_float4(c.t, __uint_as_float(c.idx), c.aux, __uint_as_float(c.aux2));
-                sl[11] = cursor;
-            }
-            // the list is done: route the slot by the material class of its hit, so that SHADE passes are homogeneous
-            uint32_t cls = 0u;
-            if (have && !to_walk && c.idx != CAND_NONE) cls = shade_class(P.mats[P.prims[c.idx].material].kind);
-            Q.push_each(have, to_walk ? (uint32_t)WQ_WALK : WQ_SHADE + cls, id, lane, failed);
+            run_top(have, ro, rd, c, cursor, walk_done, sl, id);
             prof.mark(1);
         }
     }
