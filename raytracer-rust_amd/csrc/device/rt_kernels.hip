@@ -1666,6 +1666,12 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #else
 #define MI355RT_WFCOUNT(i, n) do {} while (0)
 #endif
+#ifndef MI355RT_WF_ROUNDS
+#define MI355RT_WF_ROUNDS 3                                 // rounds x steps (ms, semesterbild / teapot 64 spp): 1x8 11.8 / 7.5, 2x8 10.7 / 6.6, 3x8 10.4 / 6.4, 4x8 10.4 / 6.3, 8x8 10.7 / 6.6, 3x12 10.7 / 6.4
+#endif
+#ifndef MI355RT_WF_STEPS
+#define MI355RT_WF_STEPS 8
+#endif
     // TOP: hittable.rs:45-58 from the slot's cursor; a mesh whose root box is hit sends the ray to WALK; at the end of the list the
     // slot is routed by the material class of its hit, so that SHADE passes are homogeneous.  Run by SHADE passes on the rays they
     // have just generated (still in registers) and by TOP1 passes on the slots whose walk is back.
@@ -1689,8 +1695,27 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                             mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);       // the root box, here: most rays miss it
                             if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
                             else {
-                                reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(root), c.t, __uint_as_float(0xFFFFFFFFu), 0.f);
-                                to_walk = true; advance = false;
+#ifndef MI355RT_WF_INLINE_MIN
+#define MI355RT_WF_INLINE_MIN 32                            // lanes inside the root box for the first steps of the walk to run right here (65: never)
+#endif
+#ifndef MI355RT_WF_INLINE_STEPS
+#define MI355RT_WF_INLINE_STEPS 8
+#endif
+                                bool parked = false;
+                                if (MI355RT_WF_INLINE_MIN <= 64 && (uint32_t)__popcll(__ballot(true)) >= (uint32_t)MI355RT_WF_INLINE_MIN) {
+#pragma unroll 1
+                                    for (int u = 0; u < MI355RT_WF_INLINE_STEPS; ++u) {
+                                        if (mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
+                                        if (mt.node == NODE_END) break;
+                                        mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);
+                                    }
+                                    if (mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
+                                    if (mt.node == NODE_END) { mesh_accept(i, mt, rd, EPS, c); parked = true; }      // the whole walk fitted: the list goes on
+                                    else reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(mt.node), mt.best_t, __uint_as_float(mt.best_tri), 0.f);
+                                } else {
+                                    reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(root), c.t, __uint_as_float(0xFFFFFFFFu), 0.f);
+                                }
+                                if (!parked) { to_walk = true; advance = false; }
                             }
                         } else {
                             const float4 w = reinterpret_cast<const float4*>(sl)[4];
@@ -1831,12 +1856,6 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 mesh_setup(pr, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.f, m);                            // the object-space ray, as TOP computed it
                 m.node = __float_as_uint(w.x); m.best_t = w.y; m.best_tri = __float_as_uint(w.z);
             }
-#ifndef MI355RT_WF_ROUNDS
-#define MI355RT_WF_ROUNDS 3                                 // rounds x steps (ms, semesterbild / teapot 64 spp): 1x8 11.8 / 7.5, 2x8 10.7 / 6.6, 3x8 10.4 / 6.4, 4x8 10.4 / 6.3, 8x8 10.7 / 6.6, 3x12 10.7 / 6.4
-#endif
-#ifndef MI355RT_WF_STEPS
-#define MI355RT_WF_STEPS 8
-#endif
             for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
                 if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
 #pragma unroll
