@@ -30,7 +30,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 CXX_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-pthread"]
 
 DEVICE_SRCS = [os.path.join(CSRC, "device", "rt_kernels.hip"), os.path.join(CSRC, "device", "rt_api.cpp")]
-DEVICE_DEPS = DEVICE_SRCS + [os.path.join(CSRC, "device", "rt_device.h"), os.path.join(ROOT, "include", "mi355rt.h")]
+DEVICE_HEADERS = sorted(os.path.join(CSRC, "device", f) for f in os.listdir(os.path.join(CSRC, "device")) if f.endswith(".h"))
+DEVICE_DEPS = DEVICE_SRCS + DEVICE_HEADERS + [os.path.join(ROOT, "include", "mi355rt.h")]
 
 
 def _host_srcs():
@@ -45,11 +46,11 @@ def _host_deps():
 
 
 def kernel_hash():
-    """sha256 over everything that decides the device code: kernel sources, the shared device header and the
+    """sha256 over everything that decides the device code: the kernel source, every header of csrc/device and the
     hipcc flags.  profiles/pmc_counters.json records it, and bench.py refuses counters taken on another kernel."""
     import hashlib
     h = hashlib.sha256()
-    for f in DEVICE_SRCS[:1] + [os.path.join(CSRC, "device", "rt_device.h")]:
+    for f in DEVICE_SRCS[:1] + DEVICE_HEADERS:              # rt_kernels.hip and every header it includes (rt_device.h, rt_math.h, ...)
         h.update(open(f, "rb").read())
     h.update(" ".join(HIPCC_FLAGS).encode())
     return h.hexdigest()[:16]

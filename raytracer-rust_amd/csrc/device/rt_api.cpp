@@ -259,7 +259,7 @@ int flatten_meshes(const mi355rt_scene* sc, std::vector<DevNode>& out_nodes, std
 }
 
 // The 6 world normals a cube hit can produce (cube.rs:105-136): normalized(world_to_object^T * (+-e_k, 0)) with
-// exactly the device's operation order (xform_normal + normalized in rt_kernels.hip; this file is compiled
+// exactly the device's operation order (xform_normal + normalized in rt_intersect.h / rt_math.h; this file is compiled
 // with -ffp-contract=off too), so the kernel can select instead of recomputing sqrt and divide per hit.
 void cube_normal_table(float* d) {
     const float EPS = 1e-4f;

@@ -1,0 +1,82 @@
+// rt_math.h -- device prelude (DI, EPS, Prof) and the f32 vector helpers of vec3.rs / color.rs, operation for operation
+// Part of the device code of libmi355rt.so; included by rt_kernels.hip only (one translation unit: every kernel sees the same
+// inlined device functions, and build.kernel_hash() covers every file of this directory).
+#pragma once
+#include "rt_device.h"
+
+namespace mi355rt {
+
+
+#define DI __device__ __forceinline__
+
+constexpr float EPS = 1e-4f;                      // renderer.rs:17
+constexpr float PI_F = 3.14159265358979323846f;   // std::f32::consts::PI
+
+typedef const __attribute__((address_space(4))) DevPrim* cprim_t;   // wave-uniform reads -> s_load
+
+// Diagnostic-only cycle stamps (build with -DMI355RT_STAMPS into a separate library; the product build
+// compiles Prof to nothing).  Shares of wave time per section, summed over waves, land in stats[2..].
+#ifdef MI355RT_STAMPS
+struct Prof {
+    unsigned long long acc[6]; unsigned long long last;
+    DI void begin() { for (int i = 0; i < 6; ++i) acc[i] = 0; last = now(); }
+    DI static unsigned long long now() {
+        unsigned long long t; __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0); return t;
+    }
+    DI void mark(int i) { unsigned long long t = now(); acc[i] += t - last; last = t; }
+};
+#else
+struct Prof { DI void begin() {} DI void mark(int) {} };
+#endif
+
+
+// ---------------------------------------------------------------------------------------------------
+// vec3.rs
+// ---------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+DI f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+DI f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DI f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DI f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+DI f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }     // Color * Color
+DI f3 operator/(f3 a, f3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }     // Color / Color
+DI f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+DI f3 divf(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+DI float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }            // vec3.rs:17-19
+DI f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }  // :21-27
+DI float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }                 // :29-31
+DI float len(f3 a) { return sqrtf(len2(a)); }                                     // :33-35
+DI f3 normalized(f3 a) { float l = len(a); if (l < EPS) return a; return a * (1.0f / l); }   // :37-44
+DI bool near_zero(f3 a) { const float S = 1e-8f; return fabsf(a.x) < S && fabsf(a.y) < S && fabsf(a.z) < S; }  // :63-66
+DI bool has_nan(f3 a) { return (a.x != a.x) || (a.y != a.y) || (a.z != a.z); }
+DI bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+DI f3 nan3() { float n = __builtin_nanf(""); return mk(n, n, n); }
+DI f3 splat(float v) { return mk(v, v, v); }
+DI f3 sqrt3(f3 a) { return mk(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)); }
+DI f3 to_world(f3 local, f3 normal) {                                             // vec3.rs:72-81
+    f3 up = (fabsf(normal.z) < 0.999f) ? mk(0.f, 0.f, 1.f) : mk(0.f, 1.f, 0.f);
+    f3 tangent = normalized(cross(normal, up));
+    f3 bitangent = cross(normal, tangent);
+    return (tangent * local.x + bitangent * local.y) + normal * local.z;
+}
+DI float clamp01(float v) { if (v < 0.0f) return 0.0f; if (v > 1.0f) return 1.0f; return v; }   // f32::clamp, NaN stays
+DI uint32_t as_u32_sat(float v) {                                                 // Rust `as u32`
+    if (!(v == v) || v <= 0.0f) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+DI int32_t as_i32_sat(float v) {                                                  // Rust `as i32`
+    if (!(v == v)) return 0;
+    if (v <= -2147483648.0f) return (int32_t)0x80000000;
+    if (v >= 2147483648.0f) return 0x7FFFFFFF;
+    return (int32_t)v;
+}
+DI uint32_t color_to_u32(f3 c) {                                                  // color.rs:87-93
+    c.x = clamp01(c.x); c.y = clamp01(c.y); c.z = clamp01(c.z);
+    return (as_u32_sat(c.x * 255.0f) << 16) | (as_u32_sat(c.y * 255.0f) << 8) | as_u32_sat(c.z * 255.0f);
+}
+
+
+}  // namespace mi355rt

@@ -1,0 +1,397 @@
+// rt_wavefront.h -- k_render_ctr_wf: path state in LDS slots, stages as queues (the default for scenes with meshes)
+// Part of the device code of libmi355rt.so; included by rt_kernels.hip only (one translation unit: every kernel sees the same
+// inlined device functions, and build.kernel_hash() covers every file of this directory).
+#pragma once
+
+namespace mi355rt {
+
+// ===================================================================================================
+// k_render_ctr_wf -- the path tracer as a WAVEFRONT inside one workgroup: path state lives in LDS, stages are queues.
+//
+// The state machine and the pool kernel keep a path in the registers of ONE lane for its whole life, so every pass of every
+// stage runs with whatever lanes of that wave happen to be in that stage (measured: 0.40 of the lanes on semesterbild).  Here
+// the CU's workgroup owns WF_PATHS path slots in LDS (20 dwords each) and queues of slot numbers -- FREE, WALK (a BVH walk in
+// progress), TOP1 (a ray whose walk is back), SHADE x 4 material classes.  Every wave loops: look at the queue lengths, choose a
+// stage, pop up to 64 of its slots, load what that stage needs, run the stage with (nearly) all lanes busy, store what changed,
+// push each slot to the queue of its next stage.  (A new ray has no queue of its own: the SHADE pass that generates it walks the
+// head of the list for it right away.)  A path therefore migrates between waves;
+// per path the arithmetic is exactly that of the other kernels (same device functions, same inputs, same order), so images
+// are bit-identical.  Regeneration stays in SHADE: a finished path's slot is refilled from the wave's own work cursor in the
+// same pass, and SHADE passes top themselves up from the FREE queue.
+// Queues: one ring of 1 024 u32 per stage (> WF_PATHS, a slot is in at most one queue), `tail` reserved by ds_add, `head`
+// advanced by ds_cmpst so that a pop never takes more than is there; an entry is written after its ticket is reserved, so a
+// popper may have to wait a few cycles for it (bounded spin) and writes EMPTY back; a pusher whose entry is still occupied (the
+// popper of the previous ring revolution has reserved it but not read it yet) waits for that popper, so no slot number is ever lost.
+// No barrier after start-up.  A wave leaves when its work cursor is exhausted and no path is alive in the workgroup.
+// ===================================================================================================
+// Two workgroups of 12 waves per CU (24 waves = 6 per SIMD at 80 VGPRs), 832 slots each: the passes begin with a chain of
+// dependent LDS round trips (pop, ring entry, slot) and the walk reads its nodes from L1/L2, so waves to switch to are worth more
+// than registers.  Measured (semesterbild / teapot, 800x600x64, ms): 1 x 16 waves, 1 728 slots 11.60 / 7.42;  2 x 12 waves,
+// 832 slots each 10.65 / 6.65;  3 x 8 waves, 512 each 11.33 / 6.86;  2 x 14 at 72 VGPRs 14.8 / 9.8 and 2 x 16 at 64 VGPRs
+// 15.3 / 9.0 (spills);  2 x 10 at 96 VGPRs 15.2 / 9.7;  1 x 16 waves with 960 fat slots (36 dwords) 11.6 / 7.3.
+#ifndef MI355RT_WF_PATHS
+#define MI355RT_WF_PATHS 832                                // what fits beside seven rings (768 beside the eight there were: semesterbild +2.4 %, teapot +1.6 %)
+#endif
+#ifndef MI355RT_WF_RING
+#define MI355RT_WF_RING 1024
+#endif
+constexpr uint32_t WF_PATHS = MI355RT_WF_PATHS, WF_SLOT_WORDS = 20, WF_RING = MI355RT_WF_RING, WF_QUEUES = 7, WF_CTRL_WORDS = 32;
+constexpr uint32_t WF_EMPTY = 0xFFFFu, WF_WALK_DONE = 0x80000000u;
+// SHADE is four queues, one per material class of the hit: a pass whose slots all take the same branch of Material::scatter pays
+// for that branch only (a mixed pass pays for the sum of all branches that any of its lanes takes).
+enum : uint32_t { WQ_FREE = 0, WQ_WALK = 1, WQ_TOP1 = 2,
+                  WQ_SHADE = 3,      // + class: 0 terminal (miss / emissive / null: the path ends, the slot regenerates), 1 diffuse (Lambert,
+                                     //          checker, texture, plastic), 2 rough conductor, 3 specular (metal, dielectric)
+                  WQ_NONE = 15 };
+DI uint32_t shade_class(uint32_t kind) {
+    return (kind == MI355RT_MAT_EMISSIVE || kind == MI355RT_MAT_NULL) ? 0u
+         : (kind == MI355RT_MAT_ROUGH_GGX || kind == MI355RT_MAT_ROUGH_BECKMANN) ? 2u
+         : (kind == MI355RT_MAT_METAL || kind == MI355RT_MAT_DIELECTRIC) ? 3u : 1u;
+}
+constexpr uint32_t WF_LDS_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
+static_assert(WF_LDS_WORDS * 4u <= 163840u / 2u, "wavefront kernel LDS budget: two workgroups per CU");
+static_assert(WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "a ring holds every slot number");
+// Slot layout, 5 x 16 bytes (the less a path carries, the more paths fit, and the fill of every pass follows from their number:
+// 960 slots of 36 dwords ran SHADE at 37 of 64 lanes):  q0 ro.xyz thr.x | q1 rd.xyz thr.y | q2 thr.z sidx ray_index cursor(+WALK_DONE) |
+// q3 cand.t idx aux aux2 | q4 walk node, best_t, best_tri, -.   Recomputed instead of stored: the RNG key (from sidx), the walk's
+// object-space ray and 1/d (mesh_setup per WALK pass: +3 % instructions), |w2o d| for the (sic) t_world.
+
+struct WfQueues {
+    uint32_t* ctrl;        // [q] head, [8 + q] tail, [16] live paths, [17] error
+    uint16_t* rings;       // WF_QUEUES x WF_RING slot numbers
+    // Pop up to `want` entries of queue q for lanes [lane0, lane0 + n): returns n; those lanes get their slot in `id`.
+    // `at_least`: take nothing if fewer are there by now -- every wave reads the same queue lengths, so several decide for the
+    // same stage at once and all but the first would get scraps (measured: SHADE at 38 of 64 lanes); they look again instead.
+    DI uint32_t pop(uint32_t q, uint32_t want, uint32_t at_least, uint32_t lane, uint32_t lane0, uint32_t& id, bool& failed) const {
+        uint32_t h = 0, n = 0;
+        if (lane == 0) {
+            for (;;) {
+                h = __hip_atomic_load(&ctrl[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t t = __hip_atomic_load(&ctrl[8u + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                n = min(t - h, want);
+                if (n < at_least) { n = 0u; break; }
+                if (n == 0u || atomicCAS(&ctrl[q], h, h + n) == h) break;
+            }
+        }
+        h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h); n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+        if (lane >= lane0 && lane < lane0 + n) {
+            volatile uint16_t* e = rings + q * WF_RING + ((h + lane - lane0) & (WF_RING - 1u));
+            uint32_t v = WF_EMPTY, spins = 0;
+            for (;;) {                                                   // the pusher reserved this ticket and is about to write it
+                v = *e;
+                if (v != WF_EMPTY) break;
+                if (++spins > (1u << 20)) { failed = true; break; }
+            }
+            *e = (uint16_t)WF_EMPTY;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            id = (v == WF_EMPTY) ? 0u : v;                               // after a failed wait the wave leaves; keep the address in range until then
+        }
+        return n;
+    }
+    DI void push(uint32_t q, bool pred, uint32_t id, uint32_t lane, bool& failed) const {
+        const uint64_t m = __ballot(pred);
+        if (m == 0ull) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the slot's stores are visible before its number is
+        const uint32_t first = (uint32_t)__builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == first) base = atomicAdd(&ctrl[8u + q], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+        if (pred) {
+            volatile uint16_t* e = rings + q * WF_RING + ((base + mbcnt64(m)) & (WF_RING - 1u));
+            // The entry of ticket T is free once the popper of ticket T - WF_RING has read it and written EMPTY back.  That popper
+            // exists (a ring holds more entries than there are slots, so ticket T - WF_RING was popped before T could be reserved);
+            // if it has been held up between reserving and reading, wait for it instead of overwriting its entry.
+            uint32_t spins = 0;
+            while (*e != WF_EMPTY) { if (++spins > (1u << 20)) { failed = true; break; } }
+            *e = (uint16_t)id;
+        }
+    }
+    // Every lane with `pred` pushes its slot to ITS queue `q` (lanes may name different queues): one reservation per queue present.
+    DI void push_each(bool pred, uint32_t q, uint32_t id, uint32_t lane, bool& failed) const {
+        uint64_t rem = __ballot(pred);
+        while (rem != 0ull) {
+            const uint32_t qq = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)__builtin_ctzll(rem));
+            const bool mine = pred && q == qq;
+            push(qq, mine, id, lane, failed);
+            rem &= ~__ballot(mine);
+        }
+    }
+    DI uint32_t count(uint32_t q) const {
+        return __hip_atomic_load(&ctrl[8u + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - __hip_atomic_load(&ctrl[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+template <bool FIXED_AABB>
+DI void render_ctr_wavefront(const RenderParams& P) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_wf[WF_LDS_WORDS];
+    WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + WF_CTRL_WORDS);
+    uint32_t* const slots = s_wf + WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u;
+    cprim_t prims = (cprim_t)(P.prims);
+    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = threadIdx.x; i < WF_QUEUES * WF_RING; i += blockDim.x) Q.rings[i] = (uint16_t)((i < WF_PATHS) ? i : WF_EMPTY);   // FREE holds every slot
+    if (threadIdx.x < WF_CTRL_WORDS) Q.ctrl[threadIdx.x] = (threadIdx.x == 8u + WQ_FREE) ? WF_PATHS : 0u;
+    __syncthreads();
+
+    WorkCursor wc; wc.init();
+    uint32_t n_paths = 0, n_rays = 0, spins = 0, naps = 0;
+    Prof prof; prof.begin();
+    bool failed = false;
+#ifdef MI355RT_STAMPS
+    unsigned long long w_exec[4] = {0, 0, 0, 0}, w_lanes[4] = {0, 0, 0, 0};    // passes and slots per pass: 0 WALK, 1 TOP1, 2 (unused: there was a TOP0 stage), 3 SHADE (+ free fill)
+#define MI355RT_WFCOUNT(i, n) do { w_exec[i] += 1; w_lanes[i] += (n); } while (0)
+#else
+#define MI355RT_WFCOUNT(i, n) do {} while (0)
+#endif
+#ifndef MI355RT_WF_ROUNDS
+#define MI355RT_WF_ROUNDS 3                                 // rounds x steps (ms, semesterbild / teapot 64 spp): 1x8 11.8 / 7.5, 2x8 10.7 / 6.6, 3x8 10.4 / 6.4, 4x8 10.4 / 6.3, 8x8 10.7 / 6.6, 3x12 10.7 / 6.4
+#endif
+#ifndef MI355RT_WF_STEPS
+#define MI355RT_WF_STEPS 8
+#endif
+    // TOP: hittable.rs:45-58 from the slot's cursor; a mesh whose root box is hit sends the ray to WALK; at the end of the list the
+    // slot is routed by the material class of its hit, so that SHADE passes are homogeneous.  Run by SHADE passes on the rays they
+    // have just generated (still in registers) and by TOP1 passes on the slots whose walk is back.
+    auto run_top = [&](const bool have, const f3 ro, const f3 rd, Cand c, uint32_t cursor, bool walk_done, uint32_t* sl, const uint32_t id) {
+        bool to_walk = false;
+        for (uint32_t i = 0; i < P.n_prims; ++i) {
+            const bool mine = have && !to_walk && cursor == i;
+            if (__ballot(mine) == 0ull) continue;
+            cprim_t pr = prims + i;
+            if (mine) {
+                bool advance = true;
+                switch (pr->kind) {                                       // wave-uniform: scalar branch
+                    case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_CUBE:   hit_cube(pr, i, ro, rd, EPS, c); break;
+                    default:
+                        if (!walk_done) {
+                            MeshTrav mt; mesh_setup(pr, ro, rd, c.t, mt);
+                            const uint32_t root = mt.node;
+                            mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);       // the root box, here: most rays miss it
+                            if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
+                            else {
+#ifndef MI355RT_WF_INLINE_MIN
+#define MI355RT_WF_INLINE_MIN 32                            // lanes inside the root box for the first steps of the walk to run right here (65: never)
+#endif
+#ifndef MI355RT_WF_INLINE_STEPS
+#define MI355RT_WF_INLINE_STEPS 8
+#endif
+                                bool parked = false;
+                                if (MI355RT_WF_INLINE_MIN <= 64 && (uint32_t)__popcll(__ballot(true)) >= (uint32_t)MI355RT_WF_INLINE_MIN) {
+#pragma unroll 1
+                                    for (int u = 0; u < MI355RT_WF_INLINE_STEPS; ++u) {
+                                        if (mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
+                                        if (mt.node == NODE_END) break;
+                                        mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);
+                                    }
+                                    if (mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
+                                    if (mt.node == NODE_END) { mesh_accept(i, mt, rd, EPS, c); parked = true; }      // the whole walk fitted: the list goes on
+                                    else reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(mt.node), mt.best_t, __uint_as_float(mt.best_tri), 0.f);
+                                } else {
+                                    reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(root), c.t, __uint_as_float(0xFFFFFFFFu), 0.f);
+                                }
+                                if (!parked) { to_walk = true; advance = false; }
+                            }
+                        } else {
+                            const float4 w = reinterpret_cast<const float4*>(sl)[4];
+                            MeshTrav mt; mt.best_t = w.y; mt.best_tri = __float_as_uint(w.z); mt.len_raw = len(xform_w2o_dir(pr, rd));   // mesh_object.rs:288, again
+                            mesh_accept(i, mt, rd, EPS, c); walk_done = false;
+                        }
+                        break;
+                }
+                if (advance) ++cursor;
+            }
+        }
+        if (have) {
+            reinterpret_cast<float4*>(sl)[3] = make_float4(c.t, __uint_as_float(c.idx), c.aux, __uint_as_float(c.aux2));
+            sl[11] = cursor;
+        }
+        uint32_t cls = 0u;
+        if (have && !to_walk && c.idx != CAND_NONE) cls = shade_class(P.mats[P.prims[c.idx].material].kind);
+        Q.push_each(have, to_walk ? (uint32_t)WQ_WALK : WQ_SHADE + cls, id, lane, failed);
+    };
+    for (;;) {
+        if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[17], 1u); break; }
+        if (__hip_atomic_load(&Q.ctrl[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
+        const uint32_t cT1 = Q.count(WQ_TOP1), cW = Q.count(WQ_WALK);
+        const uint32_t cS0 = Q.count(WQ_SHADE), cS1 = Q.count(WQ_SHADE + 1u), cS2 = Q.count(WQ_SHADE + 2u), cS3 = Q.count(WQ_SHADE + 3u);
+        const uint32_t cS = cS0 + cS1 + cS2 + cS3;
+        const uint32_t cF = wc.exhausted() ? 0u : Q.count(WQ_FREE);
+        // A pass costs its instructions whatever its fill, and the stages differ in price (SHADE ~1 800 instructions, WALK ~750,
+        // TOP0 ~700, TOP1 ~400): run the stage whose pass WASTES the fewest lane-instructions, price x empty lanes.  A full queue
+        // wastes nothing; of two thin ones the cheap stage runs and the expensive one keeps filling (measured with "fullest
+        // first": SHADE ran at 39 of 64 lanes while TOP0 ran at 61).  Ties go to the later stage.
+#ifndef MI355RT_WF_POLICY
+#define MI355RT_WF_POLICY 1
+#endif
+        uint32_t stage = WQ_NONE, best = 0;
+        {
+            uint32_t waste = 0xFFFFFFFFu;
+            auto consider = [&](uint32_t q, uint32_t n, uint32_t price) {
+                if (n == 0u) return;
+                const uint32_t w = price * (64u - min(n, 64u));
+                if (w <= waste) { waste = w; stage = q; best = n; }
+            };
+            consider(WQ_WALK, cW, 11u); consider(WQ_TOP1, cT1, 4u);
+#ifndef MI355RT_WF_T0PRICE
+#define MI355RT_WF_T0PRICE 7
+#endif
+            constexpr uint32_t T0 = MI355RT_WF_T0PRICE;                  // a SHADE pass goes on with the head of the list for the rays it generates
+            consider(WQ_SHADE + 3u, cS3, 5u + T0); consider(WQ_SHADE + 2u, cS2, 10u + T0); consider(WQ_SHADE + 1u, cS1, 8u + T0);
+            consider(WQ_SHADE, cS0 + cF, 5u + T0);                      // terminal class: free slots ride along (both only regenerate)
+        }
+        if (stage == WQ_NONE) {
+            if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > POOL_SPIN_LIMIT) { failed = true; }
+            continue;
+        }
+        // There are fewer path slots (960) than lanes in the workgroup (1 024), so with every wave busy the queues stay short and
+        // the passes run under-filled (measured: SHADE at 37 of 64).  A pass costs its instructions whatever its fill, and the
+        // kernel is issue-bound: while slots are still in flight in OTHER waves (they will land in a queue soon) a wave whose best
+        // queue is short sleeps instead of running a thin pass.  Bounded: after WF_PATIENCE naps it runs what there is.
+#ifndef MI355RT_WF_MINFILL
+#define MI355RT_WF_MINFILL 48
+#endif
+#ifndef MI355RT_WF_PATIENCE
+#define MI355RT_WF_PATIENCE 0                              // measured: any napping loses (semesterbild 64 spp 11.6 -> 12.4..13.0 ms): thin passes still hide latency
+#endif
+        if (best < MI355RT_WF_MINFILL && naps < MI355RT_WF_PATIENCE) {
+            const uint32_t alive = __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (alive > cS + cT1 + cW) { ++naps; __builtin_amdgcn_s_sleep(4); continue; }
+        }
+        naps = 0;
+#ifndef MI355RT_WF_KEEP
+#define MI355RT_WF_KEEP 3                                   // a pop must still find 3/4 of what the decision saw
+#endif
+        auto keep = [](uint32_t seen) { return MI355RT_WF_KEEP == 0 ? 0u : max(1u, seen * MI355RT_WF_KEEP / 4u); };
+        spins = 0;
+        uint32_t id = 0;
+
+        if (stage >= WQ_SHADE) {
+            // ---- SHADE (one material class) + regeneration; a terminal-class pass is topped up with free slots (which only regenerate) ----
+            const uint32_t seen = stage == WQ_SHADE ? cS0 : stage == WQ_SHADE + 1u ? cS1 : stage == WQ_SHADE + 2u ? cS2 : cS3;
+            const uint32_t n = Q.pop(stage, 64u, seen == 0u ? 0u : keep(min(seen, 64u)), lane, 0u, id, failed);
+            uint32_t nf = 0;
+            if (stage == WQ_SHADE && n < 64u && !wc.exhausted()) nf = Q.pop(WQ_FREE, 64u - n, 0u, lane, n, id, failed);
+            if (n + nf == 0u) continue;
+            const bool have = lane < n, fill = lane >= n && lane < n + nf;
+            MI355RT_WFCOUNT(3, n + nf);
+            uint32_t* sl = slots + WF_SLOT_WORDS * id;
+            PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
+            ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
+            Cand c; cand_reset(c);
+            if (have) {
+                const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1];
+                const float4 d = reinterpret_cast<const float4*>(sl)[2], g = reinterpret_cast<const float4*>(sl)[3];
+                ps.ro = mk(a.x, a.y, a.z); ps.rd = mk(b.x, b.y, b.z); ps.thr = mk(a.w, b.w, d.x);
+                ps.sidx = __float_as_uint(d.y); ps.ray_index = __float_as_uint(d.z);
+                start_path(P, ps.sidx, ps.rng, ps.px, ps.py);                   // the RNG key is a function of the sample index
+                ps.rng.ray = ps.ray_index;
+                c.t = g.x; c.idx = __float_as_uint(g.y); c.aux = g.z; c.aux2 = __float_as_uint(g.w);
+            }
+            bool live = have;
+            const bool any_hit = have && c.idx != CAND_NONE;
+            Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
+            if (any_hit) finish_hit<true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
+            shade_and_regenerate<false>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
+            if (live) {                                                          // a ray to trace: continuing or freshly generated
+                reinterpret_cast<float4*>(sl)[0] = make_float4(ps.ro.x, ps.ro.y, ps.ro.z, ps.thr.x);
+                reinterpret_cast<float4*>(sl)[1] = make_float4(ps.rd.x, ps.rd.y, ps.rd.z, ps.thr.y);
+                reinterpret_cast<float4*>(sl)[2] = make_float4(ps.thr.z, __uint_as_float(ps.sidx), __uint_as_float(ps.ray_index), __uint_as_float(0u));
+                reinterpret_cast<float4*>(sl)[3] = make_float4(__builtin_inff(), __uint_as_float(CAND_NONE), 0.f, 0.f);
+            }
+            const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
+            if (lane == 0 && born != died) atomicAdd(&Q.ctrl[16], (uint32_t)(born - died));
+            Q.push(WQ_FREE, (have || fill) && !live, id, lane, failed);
+            // Every ray SHADE produces -- continuing or freshly generated -- starts at the head of the list, so the pass goes straight
+            // on with TOP for its live lanes: as homogeneous as a pass over a queue of such rays and at least as full, minus one queue
+            // round trip per ray (there was a TOP0 queue: semesterbild 9.73 -> 9.08 ms, teapot 6.49 -> 6.17 ms at 64 spp without it).
+            prof.mark(4);
+            {   Cand c0; cand_reset(c0);
+                run_top((have || fill) && live, ps.ro, ps.rd, c0, 0u, false, sl, id); }
+            prof.mark(1);
+            continue;
+        }
+
+        if (stage == WQ_WALK) {
+            // ---- WALK: two rounds of eight box tests + the pending leaves; unfinished walks go round again ----
+            const uint32_t n = Q.pop(WQ_WALK, 64u, keep(min(cW, 64u)), lane, 0u, id, failed);
+            if (n == 0u) continue;
+            const bool have = lane < n;
+            MI355RT_WFCOUNT(0, n);
+            uint32_t* sl = slots + WF_SLOT_WORDS * id;
+            MeshTrav m; m.ro = mk(0, 0, 0); m.rd = mk(0, 0, 1); m.ix = m.iy = m.iz = 0.f; m.len_raw = 0.f; m.node = NODE_END; m.best_t = 0.f;
+            m.best_tri = 0xFFFFFFFFu; m.leaf_a = m.leaf_b = 0;
+            uint32_t cursor_word = 0;
+            if (have) {
+                const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1], w = reinterpret_cast<const float4*>(sl)[4];
+                cursor_word = sl[11];
+                const DevPrim* __restrict__ pr = P.prims + (cursor_word & ~WF_WALK_DONE);                 // lanes may be in different meshes
+                mesh_setup(pr, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.f, m);                            // the object-space ray, as TOP computed it
+                m.node = __float_as_uint(w.x); m.best_t = w.y; m.best_tri = __float_as_uint(w.z);
+            }
+            for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
+                if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
+#pragma unroll
+                for (int u = 0; u < MI355RT_WF_STEPS; ++u)
+                    if (have && m.leaf_b == 0u && m.node != NODE_END) mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, m);
+                if (have && m.leaf_b != 0u) mesh_leaf(t4, EPS, m);
+            }
+            const bool done = have && m.leaf_b == 0u && m.node == NODE_END;        // (a pass always ends with its pending leaves tested: leaf_b == 0)
+            if (have) {
+                reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(m.node), m.best_t, __uint_as_float(m.best_tri), 0.f);
+                if (done) sl[11] = cursor_word | WF_WALK_DONE;
+            }
+            Q.push(WQ_WALK, have && !done, id, lane, failed);
+            prof.mark(0);
+            // (Letting the finished walks go on with the rest of the list in this pass -- the WALK -> TOP1 counterpart of the fused
+            // SHADE -> TOP0 -- was measured at thresholds of 1 / 24 / 40 finished lanes: +-0.5 %, not kept.)
+            Q.push(WQ_TOP1, done, id, lane, failed);
+            continue;
+        }
+
+        {
+            // ---- TOP1: hittable.rs:45-58 goes on from the slot's cursor (the mesh whose walk is back) ----
+            const uint32_t n = Q.pop(WQ_TOP1, 64u, keep(min(cT1, 64u)), lane, 0u, id, failed);
+            if (n == 0u) continue;
+            const bool have = lane < n;
+            MI355RT_WFCOUNT(1, n);
+            uint32_t* sl = slots + WF_SLOT_WORDS * id;
+            f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+            Cand c; cand_reset(c);
+            uint32_t cursor = 0xFFFFFFFFu; bool walk_done = false;
+            if (have) {
+                const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1], g = reinterpret_cast<const float4*>(sl)[3];
+                ro = mk(a.x, a.y, a.z); rd = mk(b.x, b.y, b.z);
+                c.t = g.x; c.idx = __float_as_uint(g.y); c.aux = g.z; c.aux2 = __float_as_uint(g.w);
+                const uint32_t cw = sl[11];
+                cursor = cw & ~WF_WALK_DONE; walk_done = (cw & WF_WALK_DONE) != 0u;
+            }
+            run_top(have, ro, rd, c, cursor, walk_done, sl, id);
+            prof.mark(1);
+        }
+    }
+    const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
+    if (lane == 0 && P.stats) {
+        atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr);
+#ifdef MI355RT_STAMPS
+        for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
+        for (int i = 0; i < 4; ++i) { atomicAdd(&P.stats[8 + 2 * i], w_exec[i]); atomicAdd(&P.stats[9 + 2 * i], w_lanes[i]); }
+#else
+        if (failed) atomicAdd(&P.stats[15], 1ull);
+#endif
+    }
+}
+#ifndef MI355RT_OCC_WF
+#define MI355RT_OCC_WF 6
+#endif
+#define MI355RT_OCC_WFK __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_WF, MI355RT_OCC_WF)))
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true>(P); }
+
+
+}  // namespace mi355rt
