@@ -79,7 +79,8 @@ DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     float denom = dot(n, rd);
     float t = (pr->d[12] - dot(n, ro)) / denom;
     const bool candidate = !(fabsf(denom) < EPS) && !(t <= t_min || t >= c.t);
-#ifndef MI355RT_QUAD_BRANCHY                               // branch-free form: cornell 19.74 -> 19.61 ms, veach-mis +-0 (with the 4-register candidate)
+    // branch-free in the source: cornell 19.74 -> 19.61 ms, veach-mis +-0 with the 4-register candidate (the compiler still branches
+    // around the parallelogram test where a whole wave can skip it)
     // every lane runs the parallelogram test; the candidate is updated by two selects (no exec-mask region, no copies per level)
     f3 hit_pos = ro + rd * t;
     f3 v = hit_pos - mk(pr->d[0], pr->d[1], pr->d[2]);
@@ -87,17 +88,6 @@ DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     float l1 = dot(v, mk(pr->d[6], pr->d[7], pr->d[8])) * pr->d[14];
     const float lo = -EPS, hi = 1.0f + EPS;
     return cand_take(c, candidate && ((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi)), i, t);
-#else
-    if (!candidate) return false;
-    f3 hit_pos = ro + rd * t;
-    f3 v = hit_pos - mk(pr->d[0], pr->d[1], pr->d[2]);
-    float l0 = dot(v, mk(pr->d[3], pr->d[4], pr->d[5])) * pr->d[13];
-    float l1 = dot(v, mk(pr->d[6], pr->d[7], pr->d[8])) * pr->d[14];
-    const float lo = -EPS, hi = 1.0f + EPS;
-    if (!((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi))) return false;
-    c.t = t; c.idx = i;
-    return true;
-#endif
 }
 
 // glam Mat4 * Vec4 pieces on the DevPrim cube/mesh record (see rt_device.h for the layout).  PrimPtr is the wave-uniform
@@ -306,10 +296,8 @@ DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__
     // Mesh-free lists: each kind only says where the hit is and which way its surface faces; HitRecord::set_face_normal
     // (hittable.rs:19-26) then runs once for all lanes of the wave, whatever their winners are (cornell -2.5 %).  With meshes in
     // the list every kind finishes its own record (measured: the shared tail costs the wavefront kernel 3-4 %).
-#ifndef MI355RT_FINISH_SHARED
-#define MI355RT_FINISH_SHARED (!HAS_MESH)
-#endif
-    if (MI355RT_FINISH_SHARED) {
+    constexpr bool shared_tail = !HAS_MESH;
+    if (shared_tail) {
         f3 p = ro + rd * c.t, outward;                                        // sphere.rs:35, plane.rs:40, quad.rs:103
         if (kind == MI355RT_PRIM_QUAD) {                                      // quad.rs:103-131
             outward = mk(pr->d[9], pr->d[10], pr->d[11]);                     // dot(ray.direction, normal): the same sum of the same products as `denom`

@@ -15,7 +15,7 @@
 //                  Randomness: counter-based Philox4x32-10 keyed by the image row, counters
 //                  (x, sample, ray index, block): every draw is a pure function of the path, so any
 //                  schedule / tiling / GPU count produces bit-identical radiance.
-//                  Output: one float4 radiance per path into the HBM workspace.
+//                  Output: three floats of radiance per path into the HBM workspace.
 //   k_resolve      per pixel, sums its spp radiance values IN SAMPLE ORDER (renderer.rs:100), scales by
 //                  1/spp (:103), sqrt-gamma, clamp, pack 0x00RRGGBB (:112-120, color.rs:87-93).
 //   k_render_ref   validation mode: one lane per image row replays the reference's sequential

@@ -18,7 +18,7 @@ namespace mi355rt {
 // per path the arithmetic is exactly that of the other kernels (same device functions, same inputs, same order), so images
 // are bit-identical.  Regeneration stays in SHADE: a finished path's slot is refilled from the wave's own work cursor in the
 // same pass, and SHADE passes top themselves up from the FREE queue.
-// Queues: one ring of 1 024 u32 per stage (> WF_PATHS, a slot is in at most one queue), `tail` reserved by ds_add, `head`
+// Queues: one ring of 1 024 u16 per stage (> WF_PATHS, a slot is in at most one queue), `tail` reserved by ds_add, `head`
 // advanced by ds_cmpst so that a pop never takes more than is there; an entry is written after its ticket is reserved, so a
 // popper may have to wait a few cycles for it (bounded spin) and writes EMPTY back; a pusher whose entry is still occupied (the
 // popper of the previous ring revolution has reserved it but not read it yet) waits for that popper, so no slot number is ever lost.
@@ -26,8 +26,8 @@ namespace mi355rt {
 // ===================================================================================================
 // Two workgroups of 12 waves per CU (24 waves = 6 per SIMD at 80 VGPRs), 832 slots each: the passes begin with a chain of
 // dependent LDS round trips (pop, ring entry, slot) and the walk reads its nodes from L1/L2, so waves to switch to are worth more
-// than registers.  Measured (semesterbild / teapot, 800x600x64, ms): 1 x 16 waves, 1 728 slots 11.60 / 7.42;  2 x 12 waves,
-// 832 slots each 10.65 / 6.65;  3 x 8 waves, 512 each 11.33 / 6.86;  2 x 14 at 72 VGPRs 14.8 / 9.8 and 2 x 16 at 64 VGPRs
+// than registers.  Measured when the kernel still had its TOP0 queue (semesterbild / teapot, 800x600x64, ms): 1 x 16 waves,
+// 1 728 slots 11.60 / 7.42;  2 x 12 waves, 832 slots each 10.65 / 6.65;  3 x 8 waves, 512 each 11.33 / 6.86;  2 x 14 at 72 VGPRs 14.8 / 9.8 and 2 x 16 at 64 VGPRs
 // 15.3 / 9.0 (spills);  2 x 10 at 96 VGPRs 15.2 / 9.7;  1 x 16 waves with 960 fat slots (36 dwords) 11.6 / 7.3.
 #ifndef MI355RT_WF_PATHS
 #define MI355RT_WF_PATHS 832                                // what fits beside seven rings (768 beside the eight there were: semesterbild +2.4 %, teapot +1.6 %)
@@ -220,13 +220,10 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         const uint32_t cS0 = Q.count(WQ_SHADE), cS1 = Q.count(WQ_SHADE + 1u), cS2 = Q.count(WQ_SHADE + 2u), cS3 = Q.count(WQ_SHADE + 3u);
         const uint32_t cS = cS0 + cS1 + cS2 + cS3;
         const uint32_t cF = wc.exhausted() ? 0u : Q.count(WQ_FREE);
-        // A pass costs its instructions whatever its fill, and the stages differ in price (SHADE ~1 800 instructions, WALK ~750,
-        // TOP0 ~700, TOP1 ~400): run the stage whose pass WASTES the fewest lane-instructions, price x empty lanes.  A full queue
-        // wastes nothing; of two thin ones the cheap stage runs and the expensive one keeps filling (measured with "fullest
-        // first": SHADE ran at 39 of 64 lanes while TOP0 ran at 61).  Ties go to the later stage.
-#ifndef MI355RT_WF_POLICY
-#define MI355RT_WF_POLICY 1
-#endif
+        // A pass costs its instructions whatever its fill, and the stages differ in price (SHADE ~1 800 instructions + ~700 for the
+        // head of the list it goes on with, WALK ~750, TOP1 ~400): run the stage whose pass WASTES the fewest lane-instructions,
+        // price x empty lanes.  A full queue wastes nothing; of two thin ones the cheap stage runs and the expensive one keeps
+        // filling (measured with "fullest first": SHADE ran at 39 of 64 lanes).  Ties go to the later stage.
         uint32_t stage = WQ_NONE, best = 0;
         {
             uint32_t waste = 0xFFFFFFFFu;
@@ -249,10 +246,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             if (++spins > POOL_SPIN_LIMIT) { failed = true; }
             continue;
         }
-        // There are fewer path slots (960) than lanes in the workgroup (1 024), so with every wave busy the queues stay short and
-        // the passes run under-filled (measured: SHADE at 37 of 64).  A pass costs its instructions whatever its fill, and the
-        // kernel is issue-bound: while slots are still in flight in OTHER waves (they will land in a queue soon) a wave whose best
-        // queue is short sleeps instead of running a thin pass.  Bounded: after WF_PATIENCE naps it runs what there is.
+        // Optional napping (off: WF_PATIENCE 0): while slots are still in flight in OTHER waves (they will land in a queue soon) a
+        // wave whose best queue is short could sleep instead of running a thin pass.  Bounded: after WF_PATIENCE naps it runs what there is.
 #ifndef MI355RT_WF_MINFILL
 #define MI355RT_WF_MINFILL 48
 #endif
