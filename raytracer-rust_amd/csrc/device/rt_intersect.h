@@ -353,8 +353,9 @@ DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
 #undef MI_RUN
     }
 }
-// CARRY_PO: the candidate keeps the cube's object-space hit point (CandP).  On for the kernel of Lambert-only scenes (cornell
-// -1.8 %); the general mesh-free kernel has no registers to spare for it (veach-mis +1.9 % with it: spills).
+// CARRY_PO: the candidate keeps the cube's object-space hit point (CandP).  On for both mesh-free kernels: the Lambert-only one
+// (cornell -1.8 % at 72 VGPRs) and the general one, which needs 80 VGPRs = 6 waves per SIMD for it (veach-mis: +1.9 % at 72 with
+// spills, -2.6 % at 80; see MI355RT_OCC_LOCKSTEP).
 template <bool HAS_MESH, bool CARRY_PO = false>
 DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris,
                   f3 ro, f3 rd, Hit& best) {

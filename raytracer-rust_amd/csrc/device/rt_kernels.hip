@@ -279,7 +279,9 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
 #define MI355RT_TRAV_BIAS 2
 #endif
 #ifndef MI355RT_OCC_LOCKSTEP
-#define MI355RT_OCC_LOCKSTEP 7                               // veach-mis: 4 -> 6.46 ms, 5 -> 6.03, 6 -> 5.79, 7 -> 5.73 (64 spp)
+#define MI355RT_OCC_LOCKSTEP 6                               // general mesh-free kernel, veach-mis 64 spp.  Round 1: 4 -> 6.46 ms, 5 -> 6.03, 6 -> 5.79,
+                                                            // 7 -> 5.73.  After the instruction diet: 7 -> 4.94, 6 -> 4.88, and with the cube hit point
+                                                            // carried (3 more registers): 7 -> 5.03 (spills), 6 -> 4.81, 5 -> 5.04
 #endif
 #if MI355RT_OCC_LOCKSTEP > 0
 #define MI355RT_OCC_LS __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_LOCKSTEP, MI355RT_OCC_LOCKSTEP)))
@@ -304,6 +306,9 @@ DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lan
 // traces one full ray per loop iteration.  Used for scenes whose top level has no mesh (cornell, veach-mis):
 // all lanes walk the same primitive list, so the iteration is divergence-free up to the hit tests.
 // ===================================================================================================
+#ifndef MI355RT_GENERAL_CARRY_PO
+#define MI355RT_GENERAL_CARRY_PO true                       // the general mesh-free kernel carries the cube hit point too (see hit_scene): pays at 80 VGPRs
+#endif
 template <bool HAS_MESH, bool SIMPLE>
 DI void render_ctr_lockstep(const RenderParams& P) {
     cprim_t prims = (cprim_t)(P.prims);
@@ -320,7 +325,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
 #endif
     for (;;) {
         Hit h; bool hit = false;                           // h is read only where `hit` says it was written: no default values to copy around
-        if (live) hit = hit_scene<HAS_MESH, SIMPLE>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
+        if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
         if (!shade_and_regenerate<SIMPLE, false>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
