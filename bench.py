@@ -139,11 +139,15 @@ def main():
     # gloo on host copies, because RCCL refuses two ranks on one GPU.  It checks the multi-rank plumbing only;
     # its numbers mean nothing and the JSON says so.
     rehearse = os.environ.get("MI355RT_BENCH_REHEARSE") == "1" and world > 1
+    # MI355RT_BENCH_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1`: the whole multi-GPU branch -- RCCL process group,
+    # barrier, all_gather_into_tensor on the launch stream, frames in flight, all_reduce of the time -- with ONE rank.  It is the
+    # only way to execute the `nccl` calls on a one-GPU box (RCCL refuses two ranks on one device); the line says so.
+    use_dist = world > 1 or (os.environ.get("MI355RT_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group(backend="gloo")
@@ -155,7 +159,7 @@ def main():
     plan = rtdist.make_plan(H, W, world)
     opt = plan.options_for(abi, rank)
     n_local_rows = len(plan.rows[rank])
-    depth_pipe = args.pipeline if args.pipeline > 0 else (2 if world > 1 else 1)
+    depth_pipe = args.pipeline if args.pipeline > 0 else (2 if use_dist else 1)
     # One frame slot = its own context (radiance workspace, work counters), output buffer and stream, so that two frames
     # never share scratch memory.  The scene is resident in HBM in every slot from here on.
     slots = []
@@ -167,7 +171,7 @@ def main():
     ctx0 = slots[0]["ctx"]
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,7 +184,7 @@ def main():
         frame += 1
         with torch.cuda.stream(s["stream"]):
             s["ctx"].render(s["local"].data_ptr(), None, opt, s["stream"].cuda_stream)     # enqueue only: no host sync inside
-            image = rtdist.gather_image(s["local"].cpu() if rehearse else s["local"], plan, rank)
+            image = rtdist.gather_image(s["local"].cpu() if rehearse else s["local"], plan, rank, always=use_dist)
 
     for _ in range(args.warmup):
         step()
@@ -198,7 +202,7 @@ def main():
         a, b, n = s["ctx"].read_timing()
         k_render_ms += a; k_resolve_ms += b; launches += n
         s["ctx"].set_timing(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -259,7 +263,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": f"synthetic (the reference's own scene file {path}; no external data)",
             "config": {"workload": args.workload, "scene": path, "width": W, "height": H, "spp": spp, "max_bounces": depth,
                        "rng": "ctr (Philox4x32-10 per ray)", "parallelism": f"row strips of {plan.strip_rows} dealt round-robin over {world} GPU(s)"
-                       + (f", RCCL {rtdist.collective_name(rehearse)} of the packed rows" if world > 1 else ""),
+                       + (f", RCCL {rtdist.collective_name(rehearse)} of the packed rows" if use_dist else ""),
                        "frames_in_flight": depth_pipe},
             "roofline": {"bound": "valu", "kernel": KERNEL_NAMES.get(variant, "k_render_ctr"),
                          "achieved": None if achieved is None else round(achieved / 1e9, 1), "peak": round(peak_inst / 1e9, 1),
@@ -281,6 +285,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             **({"tail": tail} if tail else {}),
             **({"rehearsal": "all ranks on cuda:0 over gloo -- plumbing check only, NOT a measurement"} if rehearse else {}),
+            **({"forced_dist": "one rank through the RCCL branch (process group, barrier, all_gather_into_tensor, all_reduce) -- a check of the calls, not a multi-GPU measurement"} if use_dist and world == 1 else {}),
             "kernel": {"vgprs": st.kernel_vgprs, "grid_blocks": st.grid_blocks, "block_threads": st.block_threads, "bands": st.bands},
         }
         if image_checksum is not None:
@@ -289,7 +294,7 @@ def main():
             import numpy as np
             host.write_png(args.save_png, final_image.cpu().numpy().astype(np.uint32), W, H)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     for s in slots:

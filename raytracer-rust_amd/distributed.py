@@ -66,7 +66,8 @@ def collective_name(on_host=False):
     return "all-gather" + (" (gloo, host tensors)" if on_host or dist.get_backend() != "nccl" else " over xGMI")
 
 
-def gather_image(local_rows: torch.Tensor, plan: StripPlan, rank: int, dst: int = 0, group=None, collective: str = "all_gather"):
+def gather_image(local_rows: torch.Tensor, plan: StripPlan, rank: int, dst: int = 0, group=None, collective: str = "all_gather",
+                 always: bool = False):
     """local_rows: [plan.max_rows, width] tensor (rows beyond this rank's share are padding).
     Returns the de-interleaved [height, width] image on `dst`, None elsewhere.
 
@@ -75,7 +76,7 @@ def gather_image(local_rows: torch.Tensor, plan: StripPlan, rank: int, dst: int 
     receives torch composes a rooted gather from.  The same call runs under gloo, so the CPU tests exercise exactly the
     code path of the 8-GPU run.  collective="gather" keeps the rooted form (only `dst` receives)."""
     assert local_rows.shape[0] == plan.max_rows and local_rows.shape[1] == plan.width
-    if plan.world == 1:
+    if plan.world == 1 and not always:                          # (always: run the collective even for one rank -- the one-GPU check of the RCCL branch)
         return local_rows                                       # one rank owns every row, already in order
     if collective == "all_gather":
         stacked = torch.empty((plan.world * plan.max_rows, plan.width), dtype=local_rows.dtype, device=local_rows.device)

@@ -36,3 +36,20 @@ def test_multi_argument_checks(native, oracle_mod, abi):
         device.render_multi(sc, sc.camera, sc.settings, [0, 0], abi.Options.make(n_parts=2, part=1))
     with pytest.raises(RuntimeError, match="empty"):
         device.render_multi(sc, sc.camera, sc.settings, [])
+
+
+def test_bench_runs_its_rccl_branch_with_one_rank(tmp_path):
+    """bench.py's multi-GPU branch (RCCL process group, barrier, all_gather_into_tensor on the launch stream, two frames in flight,
+    all_reduce of the step time) cannot run with two ranks on a one-GPU box -- RCCL refuses two ranks per device -- but it can run
+    with ONE: MI355RT_BENCH_FORCE_DIST=1 under torch.distributed.run.  The image must be the 1-GPU image (checksum)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI355RT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["forced_dist"] and line["n_gpus"] == 1 and line["config"]["frames_in_flight"] == 2
+    assert "RCCL all-gather over xGMI" in line["config"]["parallelism"]
+    assert line["image_checksum"] == 4377146614767
