@@ -33,6 +33,7 @@
 //
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared -pthread
 
+#include "rust_sort_unstable.hpp"
 #include "../include/mi355rt.h"
 
 #include <atomic>
@@ -337,9 +338,11 @@ std::unique_ptr<BVHNode> bvh_new(const std::vector<Tri>& tris, uint32_t* indices
         V3 c = ((tris[a].v0 + tris[a].v1) + tris[a].v2) * (1.0f / 3.0f);
         return idx(c, axis);
     };
-    // sort_unstable_by(partial_cmp, NaN -> Equal): tie order is unspecified in Rust; this oracle keeps
-    // ties in current slice order (stable), the rule DESIGN.md documents for the product builder too.
-    std::stable_sort(indices, indices + n, [&](uint32_t a, uint32_t b) { return centroid_axis(a) < centroid_axis(b); });
+    // sort_unstable_by(partial_cmp, NaN -> Equal), bvh.rs:45-53.  The order of TIES is not specified by Rust but it is
+    // deterministic, and it decides which triangles share a leaf -- i.e. which flat leaf boxes exist (App. B-1).  So the sort is
+    // restated (rust_sort_unstable.hpp: core::slice::sort::unstable of Rust 1.81+, "ipnsort"); with it the oracle's REF mode
+    // matches the reference's committed render with NO pixel further than 20/255 (0.15 % of the pixels with a stable sort).
+    rustsort::sort_unstable_by(indices, n, [&](uint32_t a, uint32_t b) { return centroid_axis(a) < centroid_axis(b); });
     size_t mid = n / 2;
     if (mid == 0 || mid == n) {
         node->triangle_indices.assign(indices, indices + n);

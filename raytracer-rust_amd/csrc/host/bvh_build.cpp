@@ -5,8 +5,8 @@
 //   split axis = x only if its extent is strictly the largest, else y if > z, else z; sort the index
 //   slice by centroid[axis] with centroid = (v0 + v1 + v2) * (1/3); split at n/2.
 // The reference topology is load-bearing for parity (zero-thickness leaf boxes
-// never hit), so this builder must not be "improved".  Tie order of Rust's sort_unstable_by is
-// unspecified; ties keep their current slice order here (std::stable_sort).
+// never hit), so this builder must not be "improved" -- down to the order of equal centroids, which Rust's
+// sort_unstable_by leaves unspecified but deterministic: the sort itself is restated (rust_sort_unstable.hpp).
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -20,6 +20,7 @@
 
 #include "../../../include/mi355rt.h"
 #include "host_common.hpp"
+#include "rust_sort_unstable.hpp"
 
 namespace mi355rt_host {
 
@@ -69,7 +70,7 @@ struct Builder {
         }
         const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
         const int axis = (ex > ey && ex > ez) ? 0 : (ey > ez ? 1 : 2);
-        std::stable_sort(idx, idx + n, [&](uint32_t a, uint32_t b) { return centroid_axis(tris[a], axis) < centroid_axis(tris[b], axis); });
+        rustsort::sort_unstable_by(idx, n, [&](uint32_t a, uint32_t b) { return centroid_axis(tris[a], axis) < centroid_axis(tris[b], axis); });   // bvh.rs:45-53
         const size_t mid = n / 2;                                              // > 0 and < n because n > 4
         const uint32_t l = slot + 1u, r = l + subtree_nodes(mid, depth + 1);
         node.left = l; node.right = r; node.first_index = 0; node.index_count = 0;
