@@ -275,8 +275,9 @@ uint32_t    mi355rt_abi_version(void);
  * ================================================================================================= */
 
 /* BVHNode::new (src/acceleration/bvh.rs:15-76) over object-space triangles: median split on the
- * largest-extent axis, leaf when <= 4 triangles or depth >= 25.  Ties in the centroid sort are kept
- * in current slice order (the reference's sort_unstable_by tie order is unspecified).
+ * largest-extent axis, leaf when <= 4 triangles or depth >= 25.  The centroid sort restates Rust's
+ * slice::sort_unstable_by (ipnsort, Rust 1.81+) including its order of equal keys, so the arrays are the tree
+ * the reference's own BVHNode::new builds (csrc/host/rust_sort_unstable.hpp).
  * Two-call pattern: pass NULL arrays to get the counts.                                           */
 int mi355rt_bvh_build(const mi355rt_triangle* triangles, uint32_t n_triangles,
                       mi355rt_bvh_node* out_nodes, uint32_t* inout_n_nodes,
