@@ -67,22 +67,28 @@ def normalized(a):
 # ---- glam restatements ----------------------------------------------------------------------------
 def quat_from_euler_yxz_deg(rx_deg, ry_deg, rz_deg):
     """Quat::from_euler(EulerRot::YXZ, ry.to_radians(), rx.to_radians(), rz.to_radians()) (parser.rs:663-668).
-    q = qy * qx * qz, evaluated in f64 on the f32 radian angles, rounded to f32 (x, y, z, w)."""
+    q = qy * qx * qz in f32 like glam: sin / cos of the f32 half angles rounded to f32, every product and sum of the scalar
+    Quat * Quat rounded to f32 (an f64 evaluation rounded once differs by an ulp here and there)."""
     rads_per_deg = F(PI_F / F(180.0))          # f32::to_radians: self * (PI / 180.0)
     a, b, c = (float(F(F(ry_deg) * rads_per_deg)), float(F(F(rx_deg) * rads_per_deg)), float(F(F(rz_deg) * rads_per_deg)))
 
-    def qmul(p, q):
+    def qmul(p, q):                         # glam Quat * Quat (scalar path), every operation rounded to f32, left to right
         px, py, pz, pw = p
         qx, qy, qz, qw = q
-        return (pw * qx + px * qw + py * qz - pz * qy,
-                pw * qy - px * qz + py * qw + pz * qx,
-                pw * qz + px * qy - py * qx + pz * qw,
-                pw * qw - px * qx - py * qy - pz * qz)
-    qy_ = (0.0, math.sin(a * 0.5), 0.0, math.cos(a * 0.5))
-    qx_ = (math.sin(b * 0.5), 0.0, 0.0, math.cos(b * 0.5))
-    qz_ = (0.0, 0.0, math.sin(c * 0.5), math.cos(c * 0.5))
+        return (F(F(F(pw * qx) + F(px * qw)) + F(py * qz)) - F(pz * qy),
+                F(F(F(pw * qy) - F(px * qz)) + F(py * qw)) + F(pz * qx),
+                F(F(F(pw * qz) + F(px * qy)) - F(py * qx)) + F(pz * qw),
+                F(F(F(pw * qw) - F(px * qx)) - F(py * qy)) - F(pz * qz))
+    def sc(angle):                          # math::sin_cos(angle * 0.5) in f32 (correctly rounded sinf / cosf)
+        h = F(F(angle) * F(0.5))
+        return F(math.sin(float(h))), F(math.cos(float(h)))
+    (sa, ca), (sb, cb), (sc_, cc) = sc(a), sc(b), sc(c)
+    Z = F(0.0)
+    qy_ = (Z, sa, Z, ca)
+    qx_ = (sb, Z, Z, cb)
+    qz_ = (Z, Z, sc_, cc)
     q = qmul(qmul(qy_, qx_), qz_)
-    return np.array(q, dtype=np.float64).astype(F)
+    return np.array([F(v) for v in q], dtype=F)
 
 
 def mat4_from_scale_rotation_translation(scale, quat, trans):

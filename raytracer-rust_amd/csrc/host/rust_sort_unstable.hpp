@@ -15,7 +15,7 @@
 //   the ancestor pivot partitions by <=; partition = swap pivot to front, cyclic Lomuto over the rest, swap pivot to num_lt;
 //   heapsort when the limit runs out.
 // Evidence that the restatement is the reference's sort: with it the oracle's replay of the reference stream matches the
-// reference's own committed render docs/semesterbild.png with NO pixel further than 20/255 and 77.7 % of the pixels exact
+// reference's own committed render docs/semesterbild.png with NO pixel further than 20/255 and 77.7 % of the pixels exact (79.4 % with the f32 quaternion of xform.hpp)
 // (std::stable_sort: 0.15 % of the pixels > 20 -- whole letter faces -- and 60.5 % exact); tests/test_oracle_golden.py.
 #pragma once
 #include <cstddef>

@@ -1,8 +1,9 @@
 // xform.hpp -- f32 math the loader needs: the reference's own Vec3 (src/vec3.rs) and the glam 0.30.3
 // pieces it calls (Cargo.lock pin; crate source is not under /root/reference, so these restate the
 // crate's published algorithms):
-//   Quat::from_euler(EulerRot::YXZ, a, b, c) = Ry(a) * Rx(b) * Rz(c)  (parser.rs:663-668).  glam's exact
-//       f32 operation order is unpinned; evaluated here in f64 and rounded once to f32.
+//   Quat::from_euler(EulerRot::YXZ, a, b, c) = Ry(a) * Rx(b) * Rz(c)  (parser.rs:663-668), in f32 like glam (an f64 evaluation
+//       rounded once differs from it by an ulp here and there; against the reference's committed render the f32 form matches
+//       1.7 % more pixels exactly -- tests/test_oracle_golden.py).
 //   Mat4::from_scale_rotation_translation, Mat4::inverse (cofactor form), Mat4 * Vec4 (column-major).
 #pragma once
 #include <cmath>
@@ -27,15 +28,16 @@ struct Mat4 { float m[16]; };                            // m[4*col + row]
 inline float to_radians(float deg) { return deg * (PI_F / 180.0f); }   // f32::to_radians
 
 inline Quat quat_from_euler_yxz(float a, float b, float c) {
-    const double ha = 0.5 * (double)a, hb = 0.5 * (double)b, hc = 0.5 * (double)c;
-    struct Q { double x, y, z, w; };
-    auto mul = [](Q p, Q q) {
-        return Q{p.w * q.x + p.x * q.w + p.y * q.z - p.z * q.y, p.w * q.y - p.x * q.z + p.y * q.w + p.z * q.x,
-                 p.w * q.z + p.x * q.y - p.y * q.x + p.z * q.w, p.w * q.w - p.x * q.x - p.y * q.y - p.z * q.z};
+    // all in f32, as glam computes it: sin_cos of the f32 half angles (correctly rounded here: via double, so the result does not
+    // depend on the platform's sinf), then the scalar Quat * Quat with every product and sum rounded to f32, left to right
+    auto sc = [](float angle, float& s_out, float& c_out) { const float h = angle * 0.5f; s_out = (float)std::sin((double)h); c_out = (float)std::cos((double)h); };
+    auto mul = [](Quat p, Quat q) {
+        return Quat{((p.w * q.x + p.x * q.w) + p.y * q.z) - p.z * q.y, ((p.w * q.y - p.x * q.z) + p.y * q.w) + p.z * q.x,
+                    ((p.w * q.z + p.x * q.y) - p.y * q.x) + p.z * q.w, ((p.w * q.w - p.x * q.x) - p.y * q.y) - p.z * q.z};
     };
-    Q qy{0.0, std::sin(ha), 0.0, std::cos(ha)}, qx{std::sin(hb), 0.0, 0.0, std::cos(hb)}, qz{0.0, 0.0, std::sin(hc), std::cos(hc)};
-    Q q = mul(mul(qy, qx), qz);
-    return {(float)q.x, (float)q.y, (float)q.z, (float)q.w};
+    float sa, ca, sb, cb, sc_, cc; sc(a, sa, ca); sc(b, sb, cb); sc(c, sc_, cc);
+    const Quat qy{0.0f, sa, 0.0f, ca}, qx{sb, 0.0f, 0.0f, cb}, qz{0.0f, 0.0f, sc_, cc};
+    return mul(mul(qy, qx), qz);
 }
 
 inline Mat4 mat4_from_scale_rotation_translation(V3 s, Quat q, V3 t) {
