@@ -38,7 +38,7 @@ def test_multi_argument_checks(native, oracle_mod, abi):
         device.render_multi(sc, sc.camera, sc.settings, [])
 
 
-def test_bench_runs_its_rccl_branch_with_one_rank(tmp_path):
+def test_bench_runs_its_rccl_branch_with_one_rank(tmp_path, native, abi):
     """bench.py's multi-GPU branch (RCCL process group, barrier, all_gather_into_tensor on the launch stream, two frames in flight,
     all_reduce of the step time) cannot run with two ranks on a one-GPU box -- RCCL refuses two ranks per device -- but it can run
     with ONE: MI355RT_BENCH_FORCE_DIST=1 under torch.distributed.run.  The image must be the 1-GPU image (checksum)."""
@@ -52,4 +52,7 @@ def test_bench_runs_its_rccl_branch_with_one_rank(tmp_path):
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["forced_dist"] and line["n_gpus"] == 1 and line["config"]["frames_in_flight"] == 2
     assert "RCCL all-gather over xGMI" in line["config"]["parallelism"]
-    assert line["image_checksum"] == 4377146614767
+    host, device = native                                                    # the same frame through the plain one-GPU path
+    sc = host.LoadedScene(os.path.join(root, "data/scenes/tungsten/cornell-box/scene.json"), 800, 600, 256, 30)
+    packed = device.render(sc, sc.camera, sc.settings, abi.Options.make())[0]
+    assert line["image_checksum"] == int(packed.astype(np.int64).sum())
