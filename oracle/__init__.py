@@ -25,7 +25,8 @@ def build(force=False):
     """g++ the oracle into oracle/_build/ (git-ignored, travels to the GPU box with the snapshot)."""
     hdr = os.path.join(_ROOT, "include", "mi355rt.h")
     if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(_SRC), os.path.getmtime(hdr))):
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(_SRC), os.path.getmtime(hdr),
+                                             os.path.getmtime(os.path.join(os.path.dirname(_SRC), "rust_sort_unstable.hpp")))):
         return _SO
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     subprocess.check_call(["g++", *CXXFLAGS, "-o", _SO, _SRC])

@@ -186,6 +186,10 @@ inline float u32_to_range11(uint32_t w) {                                       
 
 struct SamplerRef {                     // sequential row stream, call sites renderer.rs:96-97, vec3.rs:48-50,
     ChaCha12* rng;                      // material.rs:145, tungsten/materials.rs:46,247-248,275-276
+    // ln / atan / sin / cos of the microfacet sampling: evaluated in double and rounded once (the correctly rounded f32 value in all
+    // but ~1e-8 of the cases), not the platform's float functions -- the replay must not depend on whose libm runs it; the device's
+    // replay kernel does the same (rt_materials.h), and both reproduce the reference's committed render exactly.
+    static constexpr bool exact_libm = true;
     float jitter_u() { return u32_to_f01(rng->next_u32()); }
     float jitter_v() { return u32_to_f01(rng->next_u32()); }
     void begin_scatter() {}
@@ -216,6 +220,7 @@ inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, ui
 }
 
 struct SamplerCtr {
+    static constexpr bool exact_libm = false;                  // counter mode: the platform's float functions (the device uses its native ones)
     uint32_t k0, k1, x, s, ray;
     uint64_t words_drawn = 0;
     uint32_t cached_block = 0xFFFFFFFFu, cached_ray = 0xFFFFFFFFu, w[4];
@@ -820,13 +825,17 @@ template <class S> V3 sample_half_vector(bool ggx, V3 normal, float roughness, S
     float u1 = std::fmax(rng.uniform01(0), 1e-6f);
     float u2 = rng.uniform01(1);
     float theta_arg;
-    if (ggx) { float a = roughness * roughness; theta_arg = a * a * (-std::log(u1)) / (1.0f - u1); }
-    else     { theta_arg = -(roughness * roughness * std::log(u1)); }
+    auto ln = [](float x) { return S::exact_libm ? (float)std::log((double)x) : std::log(x); };
+    auto at = [](float x) { return S::exact_libm ? (float)std::atan((double)x) : std::atan(x); };
+    auto sn = [](float x) { return S::exact_libm ? (float)std::sin((double)x) : std::sin(x); };
+    auto cs = [](float x) { return S::exact_libm ? (float)std::cos((double)x) : std::cos(x); };
+    if (ggx) { float a = roughness * roughness; theta_arg = a * a * (-ln(u1)) / (1.0f - u1); }
+    else     { theta_arg = -(roughness * roughness * ln(u1)); }
     if (std::isnan(theta_arg) || std::isinf(theta_arg) || theta_arg < 0.0f) return to_world(v3(0, 0, 1), normal);
-    float theta = std::atan(std::sqrt(theta_arg));
+    float theta = at(std::sqrt(theta_arg));
     float phi = 2.0f * PI_F * u2;
-    float sin_theta = std::sin(theta), cos_theta = std::cos(theta);
-    V3 h_local = {sin_theta * std::cos(phi), sin_theta * std::sin(phi), cos_theta};
+    float sin_theta = sn(theta), cos_theta = cs(theta);
+    V3 h_local = {sin_theta * cs(phi), sin_theta * sn(phi), cos_theta};
     if (has_nan(h_local)) return to_world(v3(0, 0, 1), normal);
     return to_world(h_local, normal);
 }

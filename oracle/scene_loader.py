@@ -160,7 +160,11 @@ def camera_new(position, look_at, world_up, fov, aspect):
     right = normalized(cross(forward, normalized(world_up)))
     true_up = normalized(cross(right, forward))
     fov_rad = F(F(F(fov) * PI_F) / F(180.0))
-    half_height = F(_tanf(float(F(fov_rad / F(2.0)))))         # f32::tan -> libm tanf
+    # f32::tan.  The platform's tanf is NOT what the reference's machine computed: for fov 60 the true tangent of the f32 half
+    # angle lies 0.0004 ulp below a rounding midpoint; glibc's tanf returns the upper neighbour, the correctly rounded value is
+    # the lower one -- and with the lower one every row of the reference's committed render is reproduced exactly (the camera
+    # rays change by an ulp, which only matters where they graze the glass ball).  So: the correctly rounded tangent, via f64.
+    half_height = F(math.tan(float(F(fov_rad / F(2.0)))))
     half_width = F(half_height * F(aspect))
     cam = abi.Camera()
     cam.position[:] = [float(v) for v in position]

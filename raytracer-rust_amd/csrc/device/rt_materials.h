@@ -154,16 +154,23 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
         float u1 = fmaxf(rng.uniform01_0(), 1e-6f);
         float u2 = rng.uniform01_1();
         float theta_arg;
-        if (ggx) { float a = rough * rough; theta_arg = a * a * (-logf(u1)) / (1.0f - u1); }
-        else { theta_arg = -(rough * rough * logf(u1)); }
+        // The replay of the reference stream (Rng = RngRef) evaluates ln / atan / sin / cos in double and rounds once: practically the
+        // correctly rounded f32 value, which is what a good host libm returns.  One ulp in the sampled half vector can flip an
+        // absorb / scatter decision and with it the rest of the row's stream; with these the GPU replay reproduces the reference's
+        // committed render (tools/gpu_ref_vs_golden.py).  The counter-mode kernels keep the native f32 functions.
+        constexpr bool EXACT_LIBM = std::is_same<Rng, RngRef>::value;
+        auto ln = [](float x) { return EXACT_LIBM ? (float)log((double)x) : logf(x); };
+        if (ggx) { float a = rough * rough; theta_arg = a * a * (-ln(u1)) / (1.0f - u1); }
+        else { theta_arg = -(rough * rough * ln(u1)); }
         f3 hv;
         if ((theta_arg != theta_arg) || isinf(theta_arg) || theta_arg < 0.0f) {
             hv = to_world(mk(0.f, 0.f, 1.f), n);
         } else {
-            float theta = atanf(sqrtf(theta_arg));
+            float theta = EXACT_LIBM ? (float)atan((double)sqrtf(theta_arg)) : atanf(sqrtf(theta_arg));
             float phi = 2.0f * PI_F * u2;
             float st, ct, sp, cp;                          // sin_cos(): one argument reduction serves both values
-            sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp);
+            if (EXACT_LIBM) { st = (float)sin((double)theta); ct = (float)cos((double)theta); sp = (float)sin((double)phi); cp = (float)cos((double)phi); }
+            else { sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp); }
             f3 hl = mk(st * cp, st * sp, ct);
             hv = has_nan(hl) ? to_world(mk(0.f, 0.f, 1.f), n) : to_world(hl, n);
         }

@@ -189,7 +189,9 @@ mi355rt_camera camera_new(V3 position, V3 look_at, V3 world_up, float fov, float
     const V3 right = normalized(cross(forward, normalized(world_up)));
     const V3 true_up = normalized(cross(right, forward));
     const float fov_rad = fov * PI_F / 180.0f;
-    const float half_height = std::tan(fov_rad / 2.0f);
+    // f32::tan, correctly rounded (through double) rather than the platform's tanf: glibc's tanf returns the upper neighbour of
+    // tan(30 deg) where the correctly rounded value -- and the reference's committed render -- has the lower one
+    const float half_height = (float)std::tan((double)(fov_rad / 2.0f));
     const float half_width = half_height * aspect;
     mi355rt_camera c;
     c.position[0] = position.x; c.position[1] = position.y; c.position[2] = position.z;

@@ -129,15 +129,15 @@ def test_semesterbild_800x600x256_statistics_against_the_reference_render(native
 
 
 def test_gpu_reference_stream_replay_reproduces_the_reference_render(native, abi):
-    """MI355RT_RNG_REF on the GPU: every row consumes StdRng::seed_from_u64(y) exactly like renderer.rs:91-101, so the
-    image must reproduce docs/semesterbild.png the way the CPU oracle does (SURVEY.md section 4 thresholds): identical
-    pixels until a row's first ulp-level divergence, identical sky rows, BVH tie-order holes in < 0.5 % of pixels."""
+    """MI355RT_RNG_REF on the GPU: every row consumes StdRng::seed_from_u64(y) exactly like renderer.rs:91-101, and the HIP path
+    -- through the C ABI, on the product loader's scene and BVH -- reproduces the reference's own committed render
+    docs/semesterbild.png EXACTLY: all 480 000 pixels.  (What that took: Rust's sort_unstable_by restated in the BVH builder,
+    glam's quaternion in f32, the camera's tan correctly rounded, and in this mode ln / atan / sin / cos rounded once from double;
+    tests/test_oracle_golden.py has the story.  With the device's native float functions 594 of the 600 rows are exact.)"""
     host, device = native
     sc = host.LoadedScene(SCENES["semesterbild"])
     gp, _, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(rng_mode=abi.RNG_REF), want_linear=False)
     gold = np.array(Image.open(os.path.join(ROOT, "tests/golden/semesterbild_reference_800x600_256spp.png")).convert("RGB")).astype(np.float64)
     d = np.abs(_rgb(gp) - gold)
-    assert d.mean() <= 1.0 and abs(_rgb(gp).mean() - gold.mean()) <= 0.1
-    assert (d.max(-1) > 20).mean() <= 0.005
-    assert (d.max(-1) == 0).mean() >= 0.5 and (d.max(-1) <= 1).mean() >= 0.7
+    assert d.max() == 0, f"{(d.max(-1) != 0).sum()} of 480000 pixels differ from the reference's render (max {d.max()})"
     assert np.array_equal(gp[:100], np.full((100, 800), 0xB4B4B4, np.uint32))
