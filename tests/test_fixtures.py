@@ -2,7 +2,8 @@
 
 CPU: the oracle must still reproduce them bit-for-bit (guards the checker against drift).
 GPU: the HIP path, through the C ABI, must reproduce them with the parity tolerances of DESIGN.md --
-     bit-identical where the path uses only + - * / sqrt, <= 1e-3 per-pixel L2 otherwise.
+     bit-identical where the path uses only + - * / sqrt and everywhere in the reference-stream mode, <= 1e-3 per-pixel L2 for the
+     counter-mode renders of scenes with rough conductors (native float ln / atan / sin / cos on the device).
 """
 import os
 
@@ -46,7 +47,7 @@ def test_hip_path_reproduces_fixtures(name, tag, native, abi):
     mode = abi.RNG_CTR if tag == "ctr" else abi.RNG_REF
     packed, linear, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(rng_mode=mode))
     want_l, want_p = z[f"{tag}_linear"], z[f"{tag}_packed"]
-    if CASES[name]:
+    if CASES[name] or tag == "ref":        # the reference-stream mode rounds its ln / atan / sin / cos once from double on both sides: exact everywhere
         assert np.array_equal(linear.view(np.uint32), want_l.view(np.uint32))
         assert np.array_equal(packed, want_p)
         assert st.rays == int(z[f"{tag}_rays"][0])
