@@ -34,7 +34,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # BASELINE.json configs[1..4]; configs[0] is the CPU plumbing case
+    # BASELINE.json configs[0..4]; configs[0] is the reference's own CPU-runnable "plumbing" case (tests/test_cfg1_cornell.py pins it
+    # whole-image; here it is only selectable -- a 1.9 M-sample frame lasts 0.3 ms on the GPU and measures launch overhead, not the kernel)
+    "cornell-box-400x300x16-d4": ("data/scenes/tungsten/cornell-box/scene.json", 400, 300, 16, 4, False),
     "cornell-box-800x600x256-d30": ("data/scenes/tungsten/cornell-box/scene.json", 800, 600, 256, 30, False),
     "teapot-800x600x256-d64": ("data/scenes/tungsten/teapot/scene.json", 800, 600, 256, 64, True),
     "veach-mis-1280x720x1024-d16": ("data/scenes/tungsten/veach-mis/scene.json", 1280, 720, 1024, 16, False),

@@ -40,5 +40,26 @@ def main():
         print(name, {k: v.shape for k, v in data.items()})
 
 
+def main_cfg1():
+    """BASELINE.json configs[0] at its own size -- cornell-box 400x300, 16 spp, max_bounces 4: too large to commit as pixels
+    (1.4 MB of f32), so the fixture holds SHA-256 digests of the oracle's whole image in both RNG modes plus its work counters
+    (2.77 rays per sample).  The product loader (C++) supplies the scene: this is the CPU "plumbing" leg."""
+    import hashlib
+    import importlib
+    import json
+    host = importlib.import_module("raytracer-rust_amd.host")
+    importlib.import_module("raytracer-rust_amd.build").build_host()
+    sc = host.LoadedScene(os.path.join(ROOT, "data/scenes/tungsten/cornell-box/scene.json"), 400, 300, 16, 4)
+    doc = {"scene": "data/scenes/tungsten/cornell-box/scene.json", "width": 400, "height": 300, "spp": 16, "max_depth": 4}
+    for mode, tag in ((abi.RNG_CTR, "ctr"), (abi.RNG_REF, "ref")):
+        packed, linear, cnt = oracle.render(sc, sc.camera, sc.settings, abi.Options.make(rng_mode=mode), threads=0)
+        doc[tag] = {"packed_sha256": hashlib.sha256(packed.tobytes()).hexdigest(), "linear_sha256": hashlib.sha256(linear.tobytes()).hexdigest(),
+                    "packed_sum": int(packed.astype(np.int64).sum()), "samples": int(cnt.samples), "rays": int(cnt.rays),
+                    "depth_exhausted": int(cnt.depth_exhausted), "rng_words": int(cnt.rng_words)}
+    json.dump(doc, open(os.path.join(ROOT, "tests", "golden", "oracle_cfg1_cornell_400x300x16_d4.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(doc, indent=1))
+
+
 if __name__ == "__main__":
     main()
+    main_cfg1()
