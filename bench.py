@@ -119,6 +119,11 @@ def main():
     ap.add_argument("--save-png", default="")
     args = ap.parse_args()
 
+    # RCCL sets up its intra-node transport with HIP IPC handles; on this pool the host driver only supports dmabuf IPC, and the
+    # legacy mode fails in `hipIpcGetMemHandle: invalid argument` as soon as there are two ranks.  The variable has to be in the
+    # environment before the HIP runtime initialises, i.e. before `import torch`.  setdefault: a caller's
+    # explicit choice wins.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,6 +203,13 @@ def main():
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    # The timed renders were enqueued asynchronously (stats == NULL); a kernel that left an image incomplete is reported here
+    # (mi355rt_context_check, sticky error word) and the run ends WITHOUT a result line: a partial image is not a measurement.
+    for s in slots:
+        try:
+            s["ctx"].check()
+        except device.RenderError as e:
+            sys.exit(f"bench.py: rank {rank}: a timed render did not complete -- {e}")
     k_render_ms = k_resolve_ms = 0.0
     launches = 0
     for s in slots:

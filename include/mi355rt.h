@@ -20,6 +20,7 @@
  *   - matrices are column-major 4x4 as glam::Mat4 stores them (x_axis, y_axis, z_axis, w_axis).
  *   - the top-level primitive array is walked in array order, exactly as
  *     HittableList::hit walks `objects` (src/hittable.rs:45-58): order changes tie-breaks.
+ *   - the libraries read NO environment variables: everything that selects behaviour is in the structs below.
  */
 #ifndef MI355RT_H
 #define MI355RT_H
@@ -223,6 +224,18 @@ int  mi355rt_rows_selected(const mi355rt_settings* settings, const mi355rt_optio
 int  mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* options_or_null,
                             void* d_out_packed_rgb, void* d_out_linear_rgb_or_null,
                             void* hip_stream, mi355rt_stats* stats_or_null);
+
+/* Completion check of the asynchronous form.  render_scene is infallible (src/renderer.rs:67): it either returns the whole image or
+ * panics.  mi355rt_context_render with stats == NULL only ENQUEUES work, so a failure inside a kernel -- a wave of the wavefront
+ * kernel that gives up a bounded wait leaves paths unfinished -- cannot be returned by that call.  It is never lost: every render
+ * leaves the context's error word behind in stream order, and the next of
+ *   - mi355rt_context_check (waits for every render enqueued on this context so far),
+ *   - mi355rt_context_read_timing,
+ *   - the next mi355rt_context_render* on this context (without waiting: it sees the renders that have finished),
+ *   - the same call, when it was given stats and therefore synchronises,
+ * returns MI355RT_ERR_HIP once per failed render ("kernel watchdog ... that image is incomplete").  A caller that consumes images
+ * from the asynchronous form calls mi355rt_context_check after synchronising its stream and before using them.                     */
+int  mi355rt_context_check(mi355rt_context* ctx);
 
 /* Progressive rendering (the sample loop of src/renderer.rs:93-101 cut into chunks): trace samples
  * [sample_begin, sample_end) of every selected pixel and add them, in sample order, to the running

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -77,6 +79,9 @@ template <class T> struct DevBuf {
 
 }  // namespace
 
+struct mi355rt_context;
+static int report_device_error(mi355rt_context* ctx);
+
 struct mi355rt_context {
     int device = 0;
     int cu_count = 0;
@@ -105,7 +110,16 @@ struct mi355rt_context {
     // operation of every render; a render enqueued on ANOTHER stream waits on it first, so two streams can never touch
     // the workspaces concurrently (same stream: in-order execution already guarantees it).
     hipEvent_t done = nullptr; hipStream_t last_stream = nullptr; bool have_last = false;
-    bool want_wave_times = false;        // MI355RT_WAVE_TIMES=1 at context creation (diagnostic builds)
+    bool want_wave_times = false;        // diagnostic knob "wave_times" (stamps builds)
+    // Sticky error word.  A wave of the wavefront kernel that gives up a bounded wait (RenderParams.spin_limit_*) adds 1 to `errword`
+    // and leaves paths unfinished.  The word is never reset by a render; its value is copied into the pinned host word `h_err`
+    // behind the kernels of EVERY render (8 bytes, in stream order, before `done`), and whichever entry point looks next --
+    // the same call when it synchronises for stats, mi355rt_context_check, mi355rt_context_read_timing, or the next render on
+    // this context -- compares it with what has been reported and returns MI355RT_ERR_HIP once per failed render.
+    DevBuf<unsigned long long> errword; unsigned long long* h_err = nullptr; unsigned long long err_reported = 0;
+    uint32_t spin_limit_idle = SPIN_LIMIT_IDLE, spin_limit_entry = SPIN_LIMIT_ENTRY;   // diagnostic knobs "spin_idle" / "spin_entry"
+    int forced_variant = -1;             // diagnostic knob "kernel": applied by set_scene when the scene allows it
+    int knob_inline_steps = -1;          // diagnostic knob "inline_steps" (reference build's state machine / pool kernels)
     // timing pool (mi355rt_context_set_timing): event triples recorded around every kernel pair without
     // synchronising; mi355rt_context_read_timing sums them after the caller's own stream sync.
     bool timing = false;
@@ -116,6 +130,18 @@ struct mi355rt_context {
         return pool[pool_used++];
     }
 };
+
+// Compares the host copy of the context's error word with what has already been reported.  The copy is refreshed in stream order
+// behind every render, so after a wait on `done` it covers every render enqueued so far; without a wait it covers those that
+// have finished.
+static int report_device_error(mi355rt_context* ctx) {
+    if (!ctx->h_err) return MI355RT_OK;
+    const unsigned long long now = *(volatile unsigned long long*)ctx->h_err;
+    if (now == ctx->err_reported) return MI355RT_OK;
+    const unsigned long long n = now - ctx->err_reported;
+    ctx->err_reported = now;
+    return fail(MI355RT_ERR_HIP, "kernel watchdog: " + std::to_string(n) + " wave(s) waited too long in an earlier render on this context and gave up -- that image is incomplete");
+}
 
 namespace {
 
@@ -374,30 +400,61 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         simple_mats = simple_mats && (k == MI355RT_MAT_LAMBERT_SOLID || k == MI355RT_MAT_EMISSIVE || k == MI355RT_MAT_NULL);
     }
     ctx->has_mesh = has_mesh;
-    // Scenes with meshes: the wavefront kernel (path state in LDS, stage queues).  The in-wave state machine (2)
-    // and the walk-pool kernel (5) stay selectable through MI355RT_KERNEL for A/B runs and as the tests' bit-identity references.
+    // Scenes with meshes: the wavefront kernel (path state in LDS, stage queues).  No mesh: a lockstep kernel, the
+    // Lambert-only instantiation when the materials allow it.  The library reads NO environment variables; the diagnostic hook
+    // mi355rt_debug_set_knob("kernel", v) may name another variant this library was built with (tests, tools/ab*.py).
     ctx->variant = has_mesh ? KERNEL_WAVEFRONT : (simple_mats ? KERNEL_LOCKSTEP_SIMPLE : KERNEL_LOCKSTEP);
-    if (const char* e = std::getenv("MI355RT_KERNEL")) {            // A/B override (tools/): 0 lockstep, 1 lockstep+mesh, 2 state machine, 3 lockstep simple, 5 walk pool
-        const int v = std::atoi(e);
-        const bool ok = (v == KERNEL_LOCKSTEP && !has_mesh) || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || (v == KERNEL_POOL && has_mesh) || v == KERNEL_WAVEFRONT ||
-                        (v == KERNEL_LOCKSTEP_SIMPLE && !has_mesh && simple_mats);
-        if (ok) ctx->variant = (uint32_t)v;
+    if (ctx->forced_variant >= 0) {
+        const uint32_t v = (uint32_t)ctx->forced_variant;
+        const bool ok = render_ctr_variant_built(v) &&
+                        ((v == KERNEL_LOCKSTEP && !has_mesh) || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || (v == KERNEL_POOL && has_mesh) || v == KERNEL_WAVEFRONT ||
+                         (v == KERNEL_LOCKSTEP_SIMPLE && !has_mesh && simple_mats));
+        if (ok) ctx->variant = v;
     }
-    // Root-box test right at mesh set-up: the pool kernel always (rays that miss the root never leave their wave: 19.6 -> 15.5 ms on
-    // semesterbild); the state machine when several meshes share the list (teapot +5..12 %; a single mesh loses 5-10 %).
-    ctx->inline_steps = (ctx->variant == KERNEL_POOL || n_mesh_prims >= 2) ? 1u : 0u;
-    if (const char* e = std::getenv("MI355RT_INLINE_STEPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->inline_steps = (uint32_t)v; }
-    ctx->trav_min = 24;
-    if (const char* e = std::getenv("MI355RT_GUIDED_MULT")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->guided_mult = (uint32_t)v; }
-    if (const char* e = std::getenv("MI355RT_TRAV_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->trav_min = (uint32_t)v; }
-    if (const char* e = std::getenv("MI355RT_WALKERS")) { const int v = std::atoi(e); if (v >= 4 && v <= 12) ctx->walker_waves = (uint32_t)v; }
-    if (const char* e = std::getenv("MI355RT_POOL_PATIENCE")) { const int v = std::atoi(e); if (v >= 0 && v <= 100000) ctx->pool_patience = (uint32_t)v; }
+    // Root-box test right at mesh set-up (reference build's kernels): the pool kernel always (rays that miss the root never leave
+    // their wave: 19.6 -> 15.5 ms on semesterbild); the state machine when several meshes share the list (teapot +5..12 %; a single
+    // mesh loses 5-10 %).
+    ctx->inline_steps = ctx->knob_inline_steps >= 0 ? (uint32_t)ctx->knob_inline_steps : ((ctx->variant == KERNEL_POOL || n_mesh_prims >= 2) ? 1u : 0u);
+    return MI355RT_OK;
+}
+
+// Diagnostic knobs (mi355rt_debug_set_knob; not part of the public header).  They replace the environment variables earlier
+// rounds read at set_scene: a product library should not change behaviour with the caller's environment.
+std::mutex g_knob_mutex;
+std::map<std::string, int> g_default_knobs;
+int apply_knob(mi355rt_context* ctx, const std::string& name, int v) {
+    if (name == "kernel") { if (v < -1 || v >= (int)KERNEL_VARIANTS) return fail(MI355RT_ERR_INVALID, "knob kernel"); ctx->forced_variant = v; }
+    else if (name == "inline_steps") { if (v < -1 || v > 8) return fail(MI355RT_ERR_INVALID, "knob inline_steps"); ctx->knob_inline_steps = v; }
+    else if (name == "guided_mult") { if (v < 1 || v > 64) return fail(MI355RT_ERR_INVALID, "knob guided_mult"); ctx->guided_mult = (uint32_t)v; }
+    else if (name == "trav_min") { if (v < 1 || v > 64) return fail(MI355RT_ERR_INVALID, "knob trav_min"); ctx->trav_min = (uint32_t)v; }
+    else if (name == "walkers") { if (v < 4 || v > 12) return fail(MI355RT_ERR_INVALID, "knob walkers"); ctx->walker_waves = (uint32_t)v; }
+    else if (name == "pool_patience") { if (v < 0 || v > 100000) return fail(MI355RT_ERR_INVALID, "knob pool_patience"); ctx->pool_patience = (uint32_t)v; }
+    else if (name == "spin_idle") { if (v < 1) return fail(MI355RT_ERR_INVALID, "knob spin_idle"); ctx->spin_limit_idle = (uint32_t)v; }
+    else if (name == "spin_entry") { if (v < 1) return fail(MI355RT_ERR_INVALID, "knob spin_entry"); ctx->spin_limit_entry = (uint32_t)v; }
+    else if (name == "wave_times") ctx->want_wave_times = v != 0;
+    else return fail(MI355RT_ERR_INVALID, "unknown knob " + name);
     return MI355RT_OK;
 }
 
 }  // namespace
 
 extern "C" {
+
+// Diagnostic hook (not part of the public header).  ctx != NULL: set one knob of that context (before set_scene).  ctx == NULL: a
+// process-wide default applied to every context created afterwards -- also those the one-shot calls create; name == NULL clears
+// all defaults.  Knobs: kernel (KERNEL_* of rt_device.h, -1 = automatic), guided_mult, spin_idle, spin_entry, wave_times, and for the
+// reference build's kernels inline_steps, trav_min, walkers, pool_patience.
+int mi355rt_debug_set_knob(mi355rt_context* ctx, const char* name, int value) {
+    if (ctx) return name ? apply_knob(ctx, name, value) : fail(MI355RT_ERR_INVALID, "knob name is null");
+    std::lock_guard<std::mutex> g(g_knob_mutex);
+    if (!name) { g_default_knobs.clear(); return MI355RT_OK; }
+    mi355rt_context probe;                                            // validate name and range on a scratch context
+    const int rc = apply_knob(&probe, name, value);
+    if (rc == MI355RT_OK) g_default_knobs[name] = value;
+    return rc;
+}
+// 1 when this library holds the counter-mode kernel `variant` (the retired mesh kernels exist in the reference build only)
+int mi355rt_debug_has_variant(uint32_t variant) { return render_ctr_variant_built(variant) ? 1 : 0; }
 
 const char* mi355rt_last_error(void) { return g_err.c_str(); }
 uint32_t mi355rt_abi_version(void) { return MI355RT_ABI_VERSION; }
@@ -423,6 +480,7 @@ int mi355rt_context_create(int hip_device, mi355rt_context** out_ctx) {
     ctx->device = hip_device;
     ctx->cu_count = prop.multiProcessorCount;
     for (uint32_t v = 0; v < KERNEL_VARIANTS; ++v) {
+        if (!render_ctr_variant_built(v)) continue;                    // the retired mesh kernels exist in the tests' reference build only
         if (query_render_ctr_occupancy(v, &ctx->blocks_per_cu[v], &ctx->vgprs[v], &ctx->sgprs) != 0 || ctx->blocks_per_cu[v] <= 0) {
             delete ctx;
             return fail(MI355RT_ERR_HIP, std::string("kernel image not usable on this device (") + prop.gcnArchName + "); built for gfx950");
@@ -430,7 +488,11 @@ int mi355rt_context_create(int hip_device, mi355rt_context** out_ctx) {
     }
     for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { delete ctx; return fail(MI355RT_ERR_HIP, "hipEventCreate"); }
     if (hipEventCreateWithFlags(&ctx->done, hipEventDisableTiming) != hipSuccess) { delete ctx; return fail(MI355RT_ERR_HIP, "hipEventCreate"); }
-    ctx->want_wave_times = std::getenv("MI355RT_WAVE_TIMES") != nullptr;
+    if (ctx->errword.ensure(1) != MI355RT_OK || hipMemset(ctx->errword.p, 0, sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_err, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { mi355rt_context_destroy(ctx); return fail(MI355RT_ERR_HIP, "error word allocation"); }
+    *ctx->h_err = 0ull;
+    {   std::lock_guard<std::mutex> g(g_knob_mutex);                    // process-wide diagnostic defaults (mi355rt_debug_set_knob(NULL, ...))
+        for (const auto& kv : g_default_knobs) (void)apply_knob(ctx, kv.first, kv.second); }
     *out_ctx = ctx;
     return MI355RT_OK;
 }
@@ -440,7 +502,8 @@ void mi355rt_context_destroy(mi355rt_context* ctx) {
     (void)hipSetDevice(ctx->device);
     ctx->prims.release(); ctx->mats.release(); ctx->nodes.release(); ctx->tris.release(); ctx->rows.release();
     ctx->radiance.release(); ctx->counters.release(); ctx->stats.release(); ctx->fold_stack.release(); ctx->wave_times.release(); ctx->sky.release();
-    ctx->textures.release(); ctx->texels.release();
+    ctx->textures.release(); ctx->texels.release(); ctx->errword.release();
+    if (ctx->h_err) (void)hipHostFree(ctx->h_err);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->done) (void)hipEventDestroy(ctx->done);
     for (auto& e : ctx->pool) if (e) (void)hipEventDestroy(e);
@@ -468,6 +531,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
     if (!ctx || !ctx->have_scene) return fail(MI355RT_ERR_INVALID, "context has no scene");
     if (!d_out_packed) return fail(MI355RT_ERR_INVALID, "d_out_packed is null");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int erc = report_device_error(ctx)) return erc;              // an earlier asynchronous render on this context failed (no wait: what has finished so far)
     hipStream_t stream = (hipStream_t)hip_stream;
     const mi355rt_settings& st = ctx->settings;
     RowSel sel; int rc = select_rows(st, opt, sel); if (rc) return rc;
@@ -482,10 +546,12 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
     const bool fixed_aabb = opt && (opt->flags & MI355RT_FLAG_FIXED_AABB) != 0u;
     if (opt && (opt->flags & ~MI355RT_FLAG_FIXED_AABB) != 0u) return fail(MI355RT_ERR_INVALID, "options.flags has unknown bits");
     if (fixed_aabb && rng_mode != MI355RT_RNG_CTR) return fail(MI355RT_ERR_INVALID, "MI355RT_FLAG_FIXED_AABB needs MI355RT_RNG_CTR (the replay mode reproduces the reference as it is)");
-    const uint32_t variant = !(fixed_aabb && ctx->has_mesh) ? ctx->variant                                              // without a mesh the flag changes nothing
-                           : (ctx->variant == KERNEL_POOL ? (uint32_t)KERNEL_POOL_FIXAABB : ctx->variant == KERNEL_WAVEFRONT ? (uint32_t)KERNEL_WAVEFRONT_FIXAABB : (uint32_t)KERNEL_STATE_MACHINE_FIXAABB);
+    uint32_t variant = ctx->variant;
+    if (fixed_aabb && ctx->has_mesh) {                                // without a mesh the flag changes nothing
+        variant = ctx->variant == KERNEL_POOL ? (uint32_t)KERNEL_POOL_FIXAABB : ctx->variant == KERNEL_STATE_MACHINE ? (uint32_t)KERNEL_STATE_MACHINE_FIXAABB : (uint32_t)KERNEL_WAVEFRONT_FIXAABB;
+        if (!render_ctr_variant_built(variant)) variant = KERNEL_WAVEFRONT_FIXAABB;
+    }
     const bool pool = variant == KERNEL_POOL || variant == KERNEL_POOL_FIXAABB;
-    const bool wavefront = variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB;
     const uint64_t seed = opt ? opt->seed : 0;
     const uint32_t n_rows = (uint32_t)ctx->rows_host.size();
     if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs[variant]; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
@@ -501,7 +567,6 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
 
     double render_ms = 0, resolve_ms = 0, total_ms = 0;
     uint32_t n_bands = 0, grid_blocks = 0, block_threads = 0;
-    bool pool_kernel_ran = false;
 
     if (rng_mode == MI355RT_RNG_REF) {
         if (d_accum || s0 != 0 || s1 != st.samples_per_pixel)
@@ -558,7 +623,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;
         p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, pool ? POOL_NODE_CAP : LDS_NODE_CAP);
         p.walker_waves = ctx->walker_waves; p.pool_patience = ctx->pool_patience;
-        pool_kernel_ran = pool || wavefront;
+        p.err = ctx->errword.p; p.spin_limit_idle = ctx->spin_limit_idle; p.spin_limit_entry = ctx->spin_limit_entry;
         ResolveParams r{};
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
         r.spp = (uint32_t)spp; r.inv_spp = 1.0f / (float)s1;                             // renderer.rs:85
@@ -605,19 +670,15 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             }
         }
     }
+    // the context's error word, behind the kernels and in front of `done`: whoever waits on `done` (or finds it complete) sees it
+    HIP_TRY(hipMemcpyAsync(ctx->h_err, ctx->errword.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(ctx->done, stream));
     ctx->last_stream = stream; ctx->have_last = true;
     if (stats) {
         unsigned long long h[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(h, ctx->stats.p, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        unsigned long long watchdog = 0;                      // stats[15]: pool kernel only (the stamps build of the state machine counts lanes there)
-#ifndef MI355RT_STAMPS
-        if (pool_kernel_ran) HIP_TRY(hipMemcpy(&watchdog, ctx->stats.p + 15, sizeof watchdog, hipMemcpyDeviceToHost));
-#else
-        (void)pool_kernel_ran;
-#endif
-        if (watchdog != 0) return fail(MI355RT_ERR_HIP, "pool kernel watchdog: a wave waited too long and gave up (image incomplete)");
+        if (int erc = report_device_error(ctx)) return erc;          // a wave of THIS render gave up: the image is incomplete
         stats->render_kernel_ms = render_ms; stats->resolve_kernel_ms = resolve_ms; stats->total_ms = total_ms;
         stats->samples = h[0]; stats->rays = h[1];
         stats->bands = n_bands; stats->grid_blocks = grid_blocks; stats->block_threads = block_threads;
@@ -715,7 +776,14 @@ int mi355rt_context_read_timing(mi355rt_context* ctx, double* render_kernel_ms, 
     if (resolve_kernel_ms) *resolve_kernel_ms = c;
     if (launches) *launches = ctx->timed_launches;
     ctx->pool_used = 0; ctx->timed_launches = 0;
-    return MI355RT_OK;
+    return mi355rt_context_check(ctx);                               // the timed renders must also have been COMPLETE renders
+}
+
+int mi355rt_context_check(mi355rt_context* ctx) {
+    if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->have_last) HIP_TRY(hipEventSynchronize(ctx->done));     // every render enqueued so far has finished and left its error word
+    return report_device_error(ctx);
 }
 
 int mi355rt_render(const mi355rt_scene* scene, const mi355rt_camera* camera, const mi355rt_settings* settings,

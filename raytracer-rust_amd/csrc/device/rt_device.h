@@ -82,6 +82,8 @@ struct RenderParams {
     float* radiance;             // 3 floats per band sample
     uint32_t* batch_counter;     // WORK_SHARDS counters (WORK_SHARD_STRIDE words apart): next unclaimed sample of each shard; zeroed per band
     unsigned long long* stats;   // [0] = paths started, [1] = rays traced
+    unsigned long long* err;     // sticky per-context failure count: a wave that gave up a bounded wait adds 1 (never reset by a render;
+                                 // the host compares it with what it has already reported -- rt_api.cpp, check_device_error)
     unsigned long long* wave_times;  // diagnostic builds only: WAVE_TIME_WORDS u64 per wave; null otherwise
     uint32_t n_prims, n_mats;
     float miss[3];
@@ -99,7 +101,11 @@ struct RenderParams {
     uint32_t lds_nodes;          // state-machine kernel: nodes [0, lds_nodes) are read from the workgroup's LDS copy (<= LDS_NODE_CAP)
     uint32_t walker_waves;       // pool kernel: waves of each workgroup that only walk (4 .. 12 of 16)
     uint32_t pool_patience;      // pool kernel: polls a producer waits for more results before it runs an under-filled pass
+    uint32_t spin_limit_idle;    // wavefront / pool kernels: polls without progress before a wave gives up (SPIN_LIMIT_IDLE; a diagnostic hook lowers it)
+    uint32_t spin_limit_entry;   // wavefront kernel: polls of one ring entry before a lane gives up (SPIN_LIMIT_ENTRY)
 };
+constexpr uint32_t SPIN_LIMIT_IDLE = 1u << 22;    // watchdog bounds: seconds of polling, never reached by a healthy launch
+constexpr uint32_t SPIN_LIMIT_ENTRY = 1u << 20;
 
 // Which counter-mode kernel serves a scene
 enum : uint32_t {
@@ -154,6 +160,7 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
 int launch_resolve(const ResolveParams& p, void* stream);
 int launch_render_ref(const RefParams& p, void* stream);
 int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs);
+bool render_ctr_variant_built(uint32_t variant);   // false for the retired mesh kernels in the product library (they live in the tests' -DMI355RT_REFS build)
 #ifndef MI355RT_WF_THREADS
 #define MI355RT_WF_THREADS 768
 #endif

@@ -362,7 +362,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per
 
 }  // namespace mi355rt
 
+// The two earlier generations of the mesh path -- the in-wave state machine and the LDS walk pool -- are retired from the product
+// library: they are compiled only into the tests' reference build (-DMI355RT_REFS, build.build_device_variant("refs")), where they
+// serve as bit-identity references for the wavefront kernel.  k_render_ctr_mesh above stays: it is the product's fallback for
+// scenes beyond the wavefront kernel's packed-slot limits (rt_wavefront.h) and the simplest reference of the BVH walk.
+#ifdef MI355RT_REFS
 #include "rt_mesh_variants.h"   // k_render_ctr_sm, k_render_ctr_pool (use the shared pieces above)
+#endif
 #include "rt_wavefront.h"       // k_render_ctr_wf
 
 namespace mi355rt {
@@ -513,12 +519,22 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
         case KERNEL_LOCKSTEP_SIMPLE: hipLaunchKernelGGL(k_render_ctr_simple, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT:       hipLaunchKernelGGL(k_render_ctr_wf, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_FIXAABB: hipLaunchKernelGGL(k_render_ctr_wf_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
+#ifdef MI355RT_REFS
         case KERNEL_POOL:            hipLaunchKernelGGL(k_render_ctr_pool, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
         case KERNEL_POOL_FIXAABB:    hipLaunchKernelGGL(k_render_ctr_pool_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
         case KERNEL_STATE_MACHINE_FIXAABB: hipLaunchKernelGGL(k_render_ctr_sm_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
-        default:                     hipLaunchKernelGGL(k_render_ctr_sm, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
+        case KERNEL_STATE_MACHINE:   hipLaunchKernelGGL(k_render_ctr_sm, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
+#endif
+        default: return -1;                                  // a variant this library was not built with (render_ctr_variant_built)
     }
     return (int)hipGetLastError();
+}
+bool render_ctr_variant_built(uint32_t variant) {
+#ifdef MI355RT_REFS
+    return variant < KERNEL_VARIANTS;
+#else
+    return variant == KERNEL_LOCKSTEP || variant == KERNEL_LOCKSTEP_MESH || variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB;
+#endif
 }
 int launch_resolve(const ResolveParams& p, void* stream) {
     const uint32_t blocks = (p.band_pixels + 15u) / 16u;         // 4 waves x 4 pixels per block
@@ -530,15 +546,18 @@ int launch_render_ref(const RefParams& p, void* stream) {
     return (int)hipGetLastError();
 }
 int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs) {
+    if (!render_ctr_variant_built(variant)) return -1;
     const void* fn = variant == KERNEL_LOCKSTEP ? reinterpret_cast<const void*>(k_render_ctr_nomesh)
                    : variant == KERNEL_LOCKSTEP_MESH ? reinterpret_cast<const void*>(k_render_ctr_mesh)
                    : variant == KERNEL_LOCKSTEP_SIMPLE ? reinterpret_cast<const void*>(k_render_ctr_simple)
-                   : variant == KERNEL_STATE_MACHINE_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_sm_fixaabb)
                    : variant == KERNEL_WAVEFRONT ? reinterpret_cast<const void*>(k_render_ctr_wf)
-                   : variant == KERNEL_WAVEFRONT_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_wf_fixaabb)
+#ifdef MI355RT_REFS
+                   : variant == KERNEL_STATE_MACHINE_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_sm_fixaabb)
                    : variant == KERNEL_POOL ? reinterpret_cast<const void*>(k_render_ctr_pool)
                    : variant == KERNEL_POOL_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_pool_fixaabb)
-                                                       : reinterpret_cast<const void*>(k_render_ctr_sm);
+                   : variant == KERNEL_STATE_MACHINE ? reinterpret_cast<const void*>(k_render_ctr_sm)
+#endif
+                                                       : reinterpret_cast<const void*>(k_render_ctr_wf_fixaabb);
     int nb = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)block_threads_of(variant), 0);
     if (e != hipSuccess) return (int)e;

@@ -196,7 +196,6 @@ constexpr uint32_t POOL_RING = 1024;                        // > POOL_MAX_PRODUC
 constexpr uint32_t POOL_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t POOL_CTRL_WORDS = 16, POOL_REQ_WORDS = 12;
 constexpr uint32_t POOL_FIXED_BYTES = 4u * (POOL_CTRL_WORDS + POOL_RING + POOL_MAX_PRODUCER_LANES + 2u * POOL_MAX_PRODUCER_LANES + POOL_REQ_WORDS * POOL_MAX_PRODUCER_LANES);
-constexpr uint32_t POOL_SPIN_LIMIT = 1u << 22;              // watchdog: polls without progress before a wave gives up (seconds)
 static_assert(POOL_NODE_CAP * 32u + POOL_FIXED_BYTES <= 163840u, "pool kernel LDS budget");
 enum : uint32_t { ST_WAIT = 2 };                            // a producer lane whose walk is with the walkers (the slot of ST_TRAV)
 
@@ -297,10 +296,10 @@ DI void render_ctr_pool(const RenderParams& P) {
                 if (__hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;     // no producer left: nothing can be outstanding
                 if (__hip_atomic_load(&ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > POOL_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctrl[3], 1u); break; }
+                if (++spins > P.spin_limit_idle) { if (lane == 0) atomicOr(&ctrl[3], 1u); break; }
             }
         }
-        if (lane == 0 && P.stats && __hip_atomic_load(&ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) atomicAdd(&P.stats[15], 1ull);
+        if (lane == 0 && P.err && __hip_atomic_load(&ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) atomicAdd(P.err, 1ull);
         return;
     }
 
@@ -335,7 +334,7 @@ DI void render_ctr_pool(const RenderParams& P) {
         if (nW != 0u && nP + nS + nI < min_ready) {
             if (__hip_atomic_load(&ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > POOL_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctrl[3], 1u); failed = true; break; }
+            if (++spins > P.spin_limit_idle) { if (lane == 0) atomicOr(&ctrl[3], 1u); failed = true; break; }
             if (spins < P.pool_patience || nP + nS + nI == 0u) continue;         // waited long enough: run what is there
         }
         spins = 0;
@@ -414,8 +413,8 @@ DI void render_ctr_pool(const RenderParams& P) {
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
     if (lane == 0 && P.stats) {
         atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr);
-        if (failed) atomicAdd(&P.stats[15], 1ull);
     }
+    if (lane == 0 && P.err && failed) atomicAdd(P.err, 1ull);
 }
 __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_pool(const RenderParams P) { render_ctr_pool<false>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_pool_fixaabb(const RenderParams P) { render_ctr_pool<true>(P); }

@@ -59,6 +59,7 @@ static_assert(WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "a ring holds every slo
 struct WfQueues {
     uint32_t* ctrl;        // [q] head, [8 + q] tail, [16] live paths, [17] error
     uint16_t* rings;       // WF_QUEUES x WF_RING slot numbers
+    uint32_t entry_spins;  // bound for the wait on one ring entry (RenderParams.spin_limit_entry)
     // Pop up to `want` entries of queue q for lanes [lane0, lane0 + n): returns n; those lanes get their slot in `id`.
     // `at_least`: take nothing if fewer are there by now -- every wave reads the same queue lengths, so several decide for the
     // same stage at once and all but the first would get scraps (measured: SHADE at 38 of 64 lanes); they look again instead.
@@ -80,7 +81,7 @@ struct WfQueues {
             for (;;) {                                                   // the pusher reserved this ticket and is about to write it
                 v = *e;
                 if (v != WF_EMPTY) break;
-                if (++spins > (1u << 20)) { failed = true; break; }
+                if (++spins > entry_spins) { failed = true; break; }
             }
             *e = (uint16_t)WF_EMPTY;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -102,7 +103,7 @@ struct WfQueues {
             // exists (a ring holds more entries than there are slots, so ticket T - WF_RING was popped before T could be reserved);
             // if it has been held up between reserving and reading, wait for it instead of overwriting its entry.
             uint32_t spins = 0;
-            while (*e != WF_EMPTY) { if (++spins > (1u << 20)) { failed = true; break; } }
+            while (*e != WF_EMPTY) { if (++spins > entry_spins) { failed = true; break; } }
             *e = (uint16_t)id;
         }
     }
@@ -124,7 +125,7 @@ struct WfQueues {
 template <bool FIXED_AABB>
 DI void render_ctr_wavefront(const RenderParams& P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_wf[WF_LDS_WORDS];
-    WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + WF_CTRL_WORDS);
+    WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + WF_CTRL_WORDS); Q.entry_spins = P.spin_limit_entry;
     uint32_t* const slots = s_wf + WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u;
     cprim_t prims = (cprim_t)(P.prims);
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
@@ -243,7 +244,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         if (stage == WQ_NONE) {
             if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > POOL_SPIN_LIMIT) { failed = true; }
+            if (++spins > P.spin_limit_idle) { failed = true; }
             continue;
         }
         // Optional napping (off: WF_PATIENCE 0): while slots are still in flight in OTHER waves (they will land in a queue soon) a
@@ -272,7 +273,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             const uint32_t n = Q.pop(stage, 64u, seen == 0u ? 0u : keep(min(seen, 64u)), lane, 0u, id, failed);
             uint32_t nf = 0;
             if (stage == WQ_SHADE && n < 64u && !wc.exhausted()) nf = Q.pop(WQ_FREE, 64u - n, 0u, lane, n, id, failed);
-            if (n + nf == 0u) continue;
+            if (n + nf == 0u || __ballot(failed) != 0ull) continue;              // a failed wait: no pass on a made-up slot number, the loop head leaves
             const bool have = lane < n, fill = lane >= n && lane < n + nf;
             MI355RT_WFCOUNT(3, n + nf);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
@@ -315,7 +316,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         if (stage == WQ_WALK) {
             // ---- WALK: two rounds of eight box tests + the pending leaves; unfinished walks go round again ----
             const uint32_t n = Q.pop(WQ_WALK, 64u, keep(min(cW, 64u)), lane, 0u, id, failed);
-            if (n == 0u) continue;
+            if (n == 0u || __ballot(failed) != 0ull) continue;
             const bool have = lane < n;
             MI355RT_WFCOUNT(0, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
@@ -352,7 +353,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         {
             // ---- TOP1: hittable.rs:45-58 goes on from the slot's cursor (the mesh whose walk is back) ----
             const uint32_t n = Q.pop(WQ_TOP1, 64u, keep(min(cT1, 64u)), lane, 0u, id, failed);
-            if (n == 0u) continue;
+            if (n == 0u || __ballot(failed) != 0ull) continue;
             const bool have = lane < n;
             MI355RT_WFCOUNT(1, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
@@ -376,10 +377,11 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #ifdef MI355RT_STAMPS
         for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
         for (int i = 0; i < 4; ++i) { atomicAdd(&P.stats[8 + 2 * i], w_exec[i]); atomicAdd(&P.stats[9 + 2 * i], w_lanes[i]); }
-#else
-        if (failed) atomicAdd(&P.stats[15], 1ull);
 #endif
     }
+    // A wave that gave up a bounded wait left paths unfinished: count it in the context's sticky error word, which the host reads
+    // back behind every render (rt_api.cpp) -- the call that sees it returns MI355RT_ERR_HIP, whether or not it asked for stats.
+    if (__ballot(failed) != 0ull && lane == 0 && P.err) atomicAdd(P.err, 1ull);
 }
 #ifndef MI355RT_OCC_WF
 #define MI355RT_OCC_WF 6

@@ -13,15 +13,34 @@ from . import abi, build
 
 EXPORTS = ["mi355rt_render", "mi355rt_render_multi", "mi355rt_render_progressive", "mi355rt_context_create", "mi355rt_context_destroy", "mi355rt_context_set_scene",
            "mi355rt_rows_selected", "mi355rt_context_render", "mi355rt_context_render_progressive", "mi355rt_context_set_timing", "mi355rt_context_read_timing",
-           "mi355rt_last_error", "mi355rt_abi_version"]
+           "mi355rt_context_check", "mi355rt_last_error", "mi355rt_abi_version"]
 
 _lib = None
+_extra = {}
+
+
+def load(so):
+    """Bind another build of the device library (diagnostic / reference builds; the product path uses lib())."""
+    so = os.path.abspath(so)
+    if so not in _extra:
+        _extra[so] = _bind(so)
+    return _extra[so]
+
+
+def refs():
+    """The tests' reference build: the product sources plus the retired mesh kernels (state machine, walk pool), -DMI355RT_REFS."""
+    return load(build.build_device_variant("refs", ["MI355RT_REFS"]))
 
 
 def lib():
     global _lib
     if _lib is None:
-        so = os.environ.get("MI355RT_DEVICE_SO", build.DEVICE_SO)     # override: diagnostic builds only (tools/)
+        _lib = _bind(os.environ.get("MI355RT_DEVICE_SO", build.DEVICE_SO))     # override: diagnostic builds only (tools/)
+    return _lib
+
+
+def _bind(so):
+    if True:
         if not os.path.exists(so):
             raise RuntimeError(f"{so} is missing: the HIP extension must be built "
                                "(__graft_entry__.build()); there is no CPU fallback")
@@ -51,40 +70,58 @@ def lib():
         L.mi355rt_context_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.mi355rt_context_read_timing.restype = C.c_int
         L.mi355rt_context_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        L.mi355rt_context_check.restype = C.c_int
+        L.mi355rt_context_check.argtypes = [C.c_void_p]
+        L.mi355rt_debug_set_knob.restype = C.c_int
+        L.mi355rt_debug_set_knob.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.mi355rt_debug_has_variant.restype = C.c_int
+        L.mi355rt_debug_has_variant.argtypes = [C.c_uint32]
         if L.mi355rt_abi_version() != abi.ABI_VERSION:
             raise RuntimeError("libmi355rt.so ABI version does not match abi.py")
-        _lib = L
-    return _lib
+    return L
 
 
 class RenderError(RuntimeError):
-    def __init__(self, what, rc):
-        super().__init__(f"{what} failed ({rc}): {lib().mi355rt_last_error().decode()}")
+    def __init__(self, what, rc, library=None):
+        super().__init__(f"{what} failed ({rc}): {(library or lib()).mi355rt_last_error().decode()}")
         self.rc = rc
 
 
-def _check(rc, what):
+def _check(rc, what, library=None):
     if rc != 0:
-        raise RenderError(what, rc)
+        raise RenderError(what, rc, library)
 
 
-def render(scene, camera, settings, options=None, want_linear=True, want_stats=True):
+def set_knob(name, value, library=None):
+    """Diagnostic: process-wide default knob for every context created afterwards (also inside the one-shot calls).
+    Knobs: kernel, guided_mult, spin_idle, spin_entry, wave_times, inline_steps, trav_min, walkers, pool_patience (rt_api.cpp)."""
+    L = library or lib()
+    _check(L.mi355rt_debug_set_knob(None, name.encode(), int(value)), f"mi355rt_debug_set_knob({name})", L)
+
+
+def clear_knobs(library=None):
+    L = library or lib()
+    _check(L.mi355rt_debug_set_knob(None, None, 0), "mi355rt_debug_set_knob(clear)", L)
+
+
+def render(scene, camera, settings, options=None, want_linear=True, want_stats=True, library=None):
     """One-shot mi355rt_render with host buffers (what src/main.rs:57 would call).
     Returns (packed u32 [rows, W], linear f32 [rows, W, 3] or None, abi.Stats or None)."""
+    L = library or lib()
     sc = getattr(scene, "c", scene)
     rows = len(abi.rows_selected(settings.height, options))
     W = settings.width
     packed = np.zeros((rows, W), np.uint32)
     linear = np.zeros((rows, W, 3), np.float32) if want_linear else None
     stats = abi.Stats() if want_stats else None
-    _check(lib().mi355rt_render(C.byref(sc), C.byref(camera), C.byref(settings),
-                                C.byref(options) if options is not None else None,
-                                packed.ctypes.data, linear.ctypes.data if want_linear else None,
-                                C.byref(stats) if want_stats else None), "mi355rt_render")
+    _check(L.mi355rt_render(C.byref(sc), C.byref(camera), C.byref(settings),
+                            C.byref(options) if options is not None else None,
+                            packed.ctypes.data, linear.ctypes.data if want_linear else None,
+                            C.byref(stats) if want_stats else None), "mi355rt_render", L)
     return packed, linear, stats
 
 
-def render_multi(scene, camera, settings, devices, options=None, want_linear=True):
+def render_multi(scene, camera, settings, devices, options=None, want_linear=True, library=None):
     """mi355rt_render_multi: one process, the listed HIP devices (a device may repeat).  Same returns as render()."""
     sc = getattr(scene, "c", scene)
     rows = len(abi.rows_selected(settings.height, options)) if options is not None else settings.height
@@ -92,7 +129,7 @@ def render_multi(scene, camera, settings, devices, options=None, want_linear=Tru
     linear = np.zeros((rows, settings.width, 3), np.float32) if want_linear else None
     stats = abi.Stats()
     devs = (C.c_int * len(devices))(*devices)
-    _check(lib().mi355rt_render_multi(C.byref(sc), C.byref(camera), C.byref(settings), C.byref(options) if options is not None else None,
+    _check((library or lib()).mi355rt_render_multi(C.byref(sc), C.byref(camera), C.byref(settings), C.byref(options) if options is not None else None,
                                       devs, len(devices), packed.ctypes.data, linear.ctypes.data if want_linear else None, C.byref(stats)),
            "mi355rt_render_multi")
     return packed, linear, stats
@@ -143,60 +180,69 @@ def debug_hit(scene, rays, hip_device=0):
 class Context:
     """Resident-scene API: upload once, render many times into DEVICE buffers."""
 
-    def __init__(self, hip_device=0):
+    def __init__(self, hip_device=0, library=None):
+        self._L = library or lib()
         self._h = C.c_void_p()
-        _check(lib().mi355rt_context_create(hip_device, C.byref(self._h)), "mi355rt_context_create")
+        _check(self._L.mi355rt_context_create(hip_device, C.byref(self._h)), "mi355rt_context_create", self._L)
         self.settings = None
+
+    def set_knob(self, name, value):
+        """Diagnostic knob of this context (before set_scene); see device.set_knob."""
+        _check(self._L.mi355rt_debug_set_knob(self._h, name.encode(), int(value)), f"mi355rt_debug_set_knob({name})", self._L)
+
+    def check(self):
+        """mi355rt_context_check: waits for every render enqueued on this context and raises if a kernel left an image incomplete."""
+        _check(self._L.mi355rt_context_check(self._h), "mi355rt_context_check", self._L)
 
     def set_scene(self, scene, camera, settings):
         sc = getattr(scene, "c", scene)
-        _check(lib().mi355rt_context_set_scene(self._h, C.byref(sc), C.byref(camera), C.byref(settings)),
-               "mi355rt_context_set_scene")
+        _check(self._L.mi355rt_context_set_scene(self._h, C.byref(sc), C.byref(camera), C.byref(settings)),
+               "mi355rt_context_set_scene", self._L)
         self.settings = abi.Settings(settings.width, settings.height, settings.samples_per_pixel, settings.max_depth)
 
     def rows_selected(self, options=None):
         n = C.c_uint32()
-        _check(lib().mi355rt_rows_selected(C.byref(self.settings), C.byref(options) if options is not None else None,
-                                           C.byref(n)), "mi355rt_rows_selected")
+        _check(self._L.mi355rt_rows_selected(C.byref(self.settings), C.byref(options) if options is not None else None,
+                                           C.byref(n)), "mi355rt_rows_selected", self._L)
         return n.value
 
     def render(self, d_out_packed, d_out_linear=None, options=None, stream=None, want_stats=False):
         """d_out_*: integer device addresses (e.g. torch tensor .data_ptr()); stream: hipStream_t handle or None."""
         stats = abi.Stats() if want_stats else None
-        _check(lib().mi355rt_context_render(self._h, C.byref(options) if options is not None else None,
+        _check(self._L.mi355rt_context_render(self._h, C.byref(options) if options is not None else None,
                                             C.c_void_p(d_out_packed), C.c_void_p(d_out_linear) if d_out_linear else None,
                                             C.c_void_p(stream) if stream else None,
-                                            C.byref(stats) if want_stats else None), "mi355rt_context_render")
+                                            C.byref(stats) if want_stats else None), "mi355rt_context_render", self._L)
         return stats
 
     def render_progressive(self, sample_begin, sample_end, d_accum, d_out_packed, d_out_linear=None, options=None, stream=None, want_stats=False):
         """Samples [sample_begin, sample_end) added to the running sums in d_accum (float4 per selected pixel, device address)."""
         stats = abi.Stats() if want_stats else None
-        _check(lib().mi355rt_context_render_progressive(self._h, C.byref(options) if options is not None else None,
+        _check(self._L.mi355rt_context_render_progressive(self._h, C.byref(options) if options is not None else None,
                                                         int(sample_begin), int(sample_end), C.c_void_p(d_accum), C.c_void_p(d_out_packed),
                                                         C.c_void_p(d_out_linear) if d_out_linear else None,
                                                         C.c_void_p(stream) if stream else None,
-                                                        C.byref(stats) if stats is not None else None), "mi355rt_context_render_progressive")
+                                                        C.byref(stats) if stats is not None else None), "mi355rt_context_render_progressive", self._L)
         return stats
 
     def kernel_variant(self):
         """Diagnostic: the counter-mode kernel chosen for the resident scene (0 lockstep, 1 lockstep+mesh, 2 state machine, 3 lockstep simple)."""
         v = C.c_uint32()
-        _check(lib().mi355rt_debug_kernel_variant(self._h, C.byref(v)), "mi355rt_debug_kernel_variant")
+        _check(self._L.mi355rt_debug_kernel_variant(self._h, C.byref(v)), "mi355rt_debug_kernel_variant", self._L)
         return v.value
 
     def set_timing(self, enable=True):
-        _check(lib().mi355rt_context_set_timing(self._h, 1 if enable else 0), "mi355rt_context_set_timing")
+        _check(self._L.mi355rt_context_set_timing(self._h, 1 if enable else 0), "mi355rt_context_set_timing", self._L)
 
     def read_timing(self):
         """(render_kernel_ms, resolve_kernel_ms, launches) summed since the last read; call after syncing the stream."""
         a, b, n = C.c_double(), C.c_double(), C.c_uint32()
-        _check(lib().mi355rt_context_read_timing(self._h, C.byref(a), C.byref(b), C.byref(n)), "mi355rt_context_read_timing")
+        _check(self._L.mi355rt_context_read_timing(self._h, C.byref(a), C.byref(b), C.byref(n)), "mi355rt_context_read_timing", self._L)
         return a.value, b.value, n.value
 
     def close(self):
         if self._h:
-            lib().mi355rt_context_destroy(self._h)
+            self._L.mi355rt_context_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -70,3 +70,16 @@ def test_no_cpu_fallback_without_a_device(native, abi):
     with pytest.raises(device.RenderError) as e:
         device.render(sc, cam, st)
     assert e.value.rc == abi.ERR_NO_DEVICE
+
+
+def test_product_libraries_read_no_environment_and_hold_no_retired_kernels(native):
+    """include/mi355rt.h promises that nothing but the structs selects behaviour: neither library may import getenv.  The two
+    earlier generations of the mesh path (state machine, walk pool) are compiled into the tests' reference build only."""
+    import subprocess
+    b = pkg("build")
+    for so in (b.DEVICE_SO, b.HOST_SO):
+        undef = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+        assert "getenv" not in undef, so
+    syms = subprocess.run(["nm", b.DEVICE_SO], capture_output=True, text=True, check=True).stdout
+    kernels = set(re.findall(r"k_render_ctr_[a-z_]+", syms))
+    assert kernels == {"k_render_ctr_nomesh", "k_render_ctr_simple", "k_render_ctr_mesh", "k_render_ctr_wf", "k_render_ctr_wf_fixaabb"}, kernels

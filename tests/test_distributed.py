@@ -76,3 +76,36 @@ def test_plan_covers_every_row_once():
         for r, rr in enumerate(plan.rows):
             assert [pos[y] for y in rr] == [r * plan.max_rows + i for i in range(len(rr))]
     assert rtdist.make_plan(600, 4, 8).strip_rows * 8 * (600 // (rtdist.make_plan(600, 4, 8).strip_rows * 8)) == 600   # no padding at 8 ranks
+
+
+@pytest.mark.parametrize("W,H", [(800, 600), (1920, 1080)])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_plans_are_balanced_and_unpadded(W, H, world, abi):
+    """What bench.py does per rank for --gpus 2 / 4 / 8 at the two BASELINE image sizes (rows are the reference's unit,
+    /root/reference/src/renderer.rs:87-91): make_plan -> options_for -> (render) -> gather_image.  Load balance is the first thing an
+    8-GPU line is judged on: every rank must get the same number of rows (= samples) with zero padding rows in the gather buffer,
+    the ABI's own row selection must agree with the plan, and the de-interleave must put every row where it belongs."""
+    rtdist = pkg("distributed")
+    plan = rtdist.make_plan(H, W, world)
+    assert plan.max_rows * world == H, "padding rows in the gather buffer"
+    assert {len(r) for r in plan.rows} == {H // world}, "ranks render different numbers of rows"
+    assert 1 <= plan.strip_rows <= 4                                         # narrow strips: sky rows and object rows mix on every rank
+    for rank in range(world):
+        opt = plan.options_for(abi, rank)
+        assert (opt.strip_rows, opt.n_parts, opt.part) == (plan.strip_rows, world, rank)
+        assert abi.rows_selected(H, opt) == plan.rows[rank]                  # the library renders exactly the rows the plan gathers
+    # the de-interleave of gather_image: rank-major stacked strips -> image order (row y carries the value y)
+    stacked = torch.cat([torch.tensor(plan.rows[r], dtype=torch.int32).unsqueeze(1).expand(-1, 3) for r in range(world)])
+    image = stacked.index_select(0, plan.perm_on("cpu"))
+    assert torch.equal(image[:, 0], torch.arange(H, dtype=torch.int32))
+    # per-rank cost balance on the real picture: with strips of <= 4 rows every rank's rows are spread over the whole image height
+    for rr in plan.rows:
+        assert rr[0] < plan.strip_rows * world and rr[-1] >= H - plan.strip_rows * world
+
+
+def test_bench_exports_the_ipc_mode_before_torch_is_imported():
+    """RCCL's intra-node transport needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool (dmabuf IPC only); bench.py must have it in the
+    environment before the HIP runtime comes up, i.e. textually before its `import torch`."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def main():"):]
+    assert 0 < body.index('\n    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < body.index("\n    import torch\n")

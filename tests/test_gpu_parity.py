@@ -97,22 +97,43 @@ def test_odd_sizes_decode_exactly(W, H, spp, native, oracle_mod, abi):
     assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op)
 
 
+@pytest.fixture
+def knobs(native):
+    """Diagnostic knobs (mi355rt_debug_set_knob) as process-wide defaults of the product and the reference library, cleared afterwards."""
+    _, device = native
+    libs = []
+
+    def use(library=None, **kv):
+        L = library or device.lib()
+        if L not in libs:
+            libs.append(L)
+        device.clear_knobs(L)
+        for k, v in kv.items():
+            device.set_knob(k, v, L)
+    yield use
+    for L in libs:
+        device.clear_knobs(L)
+
+
 @pytest.mark.parametrize("name", ["teapot", "semesterbild"])
-def test_state_machine_equals_lockstep_walk(name, native, oracle_mod, abi, monkeypatch):
-    """The wave-scheduled state-machine kernel and the plain per-lane BVH loop are the same arithmetic per lane:
-    their outputs must be bit-identical (any trav_min), and identical to the oracle where the path is exact."""
+def test_mesh_kernels_equal_the_lockstep_walk(name, native, oracle_mod, abi, knobs):
+    """Every generation of the mesh path performs the same arithmetic per ray: the product's wavefront kernel (automatic choice), its
+    per-lane fallback loop k_render_ctr_mesh, and -- from the tests' reference build (-DMI355RT_REFS), where they were retired to --
+    the wave-scheduled state machine (any trav_min) and the LDS walk pool (4 and 9 walker waves) must be bit-identical to each other,
+    and identical to the oracle where the path is exact."""
     host, device = native
+    R = device.refs()
+    assert not device.lib().mi355rt_debug_has_variant(2) and not device.lib().mi355rt_debug_has_variant(5)     # retired from the product library
+    assert R.mi355rt_debug_has_variant(2) and R.mi355rt_debug_has_variant(5)
     sc = load_for_both(name, oracle_mod, host, width=96, height=64, spp=6, max_depth=12)
     outs = []
-    for env in ({"MI355RT_KERNEL": "1"}, {"MI355RT_KERNEL": "2", "MI355RT_TRAV_MIN": "1"}, {"MI355RT_KERNEL": "2", "MI355RT_TRAV_MIN": "64"}, {"MI355RT_KERNEL": "2"},
-                {"MI355RT_KERNEL": "5"}, {"MI355RT_KERNEL": "5", "MI355RT_WALKERS": "9", "MI355RT_TRAV_MIN": "1"},            # walk pool: 4 and 9 walker waves
-                {"MI355RT_KERNEL": "5", "MI355RT_INLINE_STEPS": "0", "MI355RT_POOL_PATIENCE": "500", "MI355RT_TRAV_MIN": "48"},
-                {"MI355RT_KERNEL": "7"}):                                                                                        # wavefront: path state in LDS, stage queues
-        for k in ("MI355RT_KERNEL", "MI355RT_TRAV_MIN", "MI355RT_WALKERS", "MI355RT_INLINE_STEPS", "MI355RT_POOL_PATIENCE"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make())
+    for library, kv in ((None, {"kernel": 1}), (None, {}), (None, {"kernel": 7}),
+                        (R, {"kernel": 1}), (R, {"kernel": 7}),
+                        (R, {"kernel": 2, "trav_min": 1}), (R, {"kernel": 2, "trav_min": 64}), (R, {"kernel": 2}),
+                        (R, {"kernel": 5}), (R, {"kernel": 5, "walkers": 9, "trav_min": 1}),                  # walk pool: 4 and 9 walker waves
+                        (R, {"kernel": 5, "inline_steps": 0, "pool_patience": 500, "trav_min": 48})):
+        knobs(library, **kv)
+        gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(), library=library)
         outs.append((gp, gl, st.rays))
     for gp, gl, rays in outs[1:]:
         assert np.array_equal(gl.view(np.uint32), outs[0][1].view(np.uint32)) and np.array_equal(gp, outs[0][0]) and rays == outs[0][2]
@@ -121,7 +142,7 @@ def test_state_machine_equals_lockstep_walk(name, native, oracle_mod, abi, monke
         assert np.array_equal(outs[0][1].view(np.uint32), ol.view(np.uint32)) and cnt.rays == outs[0][2]
 
 
-def test_simple_material_kernel_equals_general(native, oracle_mod, abi, monkeypatch):
+def test_simple_material_kernel_equals_general(native, oracle_mod, abi, knobs):
     """cornell has only Lambertian / Emissive materials, so set_scene picks the instantiation with the other BSDFs
     compiled out.  It must be bit-identical to the general lockstep kernel and to the oracle, and must NOT be
     picked (nor be forceable) for a scene that has any other material."""
@@ -140,9 +161,9 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, monkeypa
         return v, packed.cpu().numpy().view(np.uint32), linear.cpu().numpy(), st.rays
 
     sc = load_for_both("cornell", oracle_mod, host, width=80, height=48, spp=9, max_depth=12)
-    monkeypatch.delenv("MI355RT_KERNEL", raising=False)
+    knobs()
     v, gp, gl, rays = run(sc)
-    monkeypatch.setenv("MI355RT_KERNEL", "0")
+    knobs(kernel=0)
     v0, gp0, gl0, rays0 = run(sc)
     assert (v, v0) == (3, 0), "the simple-materials instantiation was not selected for cornell"
     assert np.array_equal(gl.view(np.uint32), gl0.view(np.uint32)) and np.array_equal(gp, gp0) and rays == rays0
@@ -150,9 +171,9 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, monkeypa
     assert np.array_equal(gl.view(np.uint32), ol.reshape(-1).view(np.uint32)) and cnt.rays == rays
 
     sv = load_for_both("veach", oracle_mod, host, width=80, height=48, spp=4, max_depth=8)
-    monkeypatch.delenv("MI355RT_KERNEL", raising=False)
+    knobs()
     vv, _, vl, _ = run(sv)
-    monkeypatch.setenv("MI355RT_KERNEL", "3")             # refused: the scene has RoughConductor materials
+    knobs(kernel=3)                                       # refused: the scene has RoughConductor materials
     vv3, _, vl3, _ = run(sv)
     assert (vv, vv3) == (0, 0)
     assert np.array_equal(vl.view(np.uint32), vl3.view(np.uint32))
@@ -203,8 +224,8 @@ def test_texture_material_scene_matches_the_oracle(native, oracle_mod, abi):
         device.render(sc, cam, st, abi.Options.make())
 
 
-@pytest.mark.parametrize("kernel", ["7", "2", "1"])
-def test_caller_built_bvh_with_fat_leaves(kernel, native, oracle_mod, abi, monkeypatch):
+@pytest.mark.parametrize("kernel", [7, 2, 1])
+def test_caller_built_bvh_with_fat_leaves(kernel, native, oracle_mod, abi, knobs):
     """The BVH crosses the ABI in the reference's shape, so a caller may hand over any tree -- also leaves with more triangles than
     the device's 6-bit leaf count holds.  Such a leaf keeps its box test as an inner node in front of a chain of chunk leaves with
     infinite bounds (rt_api.cpp, flatten_meshes).  One mesh of 150 triangles under (a) the tree the host builder makes, (b) ONE leaf
@@ -214,7 +235,8 @@ def test_caller_built_bvh_with_fat_leaves(kernel, native, oracle_mod, abi, monke
     import ctypes as C
     from fuzz_scenes import random_scene
     host, device = native
-    monkeypatch.setenv("MI355RT_KERNEL", kernel)
+    library = device.refs() if kernel == 2 else None                   # the state machine lives in the reference build
+    knobs(library, kernel=kernel)
     st = abi.Settings(48, 36, 4, 6)
     keep = []                                                           # ctypes arrays the scene points into
 
@@ -222,7 +244,7 @@ def test_caller_built_bvh_with_fat_leaves(kernel, native, oracle_mod, abi, monke
         return random_scene(abi, host, 77, exact_only=True, n_prims=6, mesh_tris=150, only_kinds=[abi.PRIM_MESH, abi.PRIM_QUAD, abi.PRIM_SPHERE])
 
     def both(sc):
-        got = device.render(sc, sc.camera, st, abi.Options.make())
+        got = device.render(sc, sc.camera, st, abi.Options.make(), library=library)
         op, ol, cnt = oracle_mod.render(sc, sc.camera, st, abi.Options.make())
         assert np.array_equal(got[1].view(np.uint32), ol.view(np.uint32)) and np.array_equal(got[0], op)
         return got

@@ -61,3 +61,68 @@ def test_one_context_on_two_streams_is_serialised(native, abi):
         torch.cuda.synchronize()
         assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
     ctx.close()
+
+
+def test_a_wave_that_gives_up_is_reported_on_the_asynchronous_path(native, abi):
+    """render_scene is infallible (/root/reference/src/renderer.rs:67): the boundary must never hand back a partial image as OK.
+    The wavefront kernel bounds every wait; the diagnostic knob `spin_idle` = 1 (through RenderParams, same product library)
+    makes a wave that finds its queues empty twice in a row give up, which leaves paths unfinished.  The render was enqueued with
+    stats == NULL, so the call itself returned OK -- the failure must surface, exactly once, in mi355rt_context_check, in
+    mi355rt_context_read_timing, at the next render on the context, and in the synchronous (stats) form; afterwards the
+    context works again, and nothing hangs or aborts."""
+    host, device = native
+    sc = host.LoadedScene(SCENES["semesterbild"], 160, 120, 16, 30)
+    n = 160 * 120
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+
+    def fresh(spin):
+        c = device.Context(0)
+        if spin:
+            c.set_knob("spin_idle", spin)
+        c.set_scene(sc, sc.camera, sc.settings)
+        assert c.kernel_variant() == 7
+        return c
+
+    good = fresh(0)
+    want = torch.zeros(n, dtype=torch.int32, device="cuda")
+    st = good.render(want.data_ptr(), None, abi.Options.make(), None, want_stats=True)
+    good.check()                                                       # a healthy context: nothing to report
+    good.close()
+
+    # (1) asynchronous render, then the explicit check
+    ctx = fresh(1)
+    ctx.render(out.data_ptr(), None, abi.Options.make(), None)         # stats == NULL: enqueue only, returns OK
+    torch.cuda.synchronize()
+    with pytest.raises(device.RenderError, match="watchdog") as e:
+        ctx.check()
+    assert e.value.rc == abi.ERR_HIP
+    ctx.check()                                                        # reported once
+    # (2) ... the next render on the context reports the previous one
+    ctx.render(out.data_ptr(), None, abi.Options.make(), None)
+    torch.cuda.synchronize()
+    with pytest.raises(device.RenderError, match="watchdog"):
+        ctx.render(out.data_ptr(), None, abi.Options.make(), None)
+    # (3) ... read_timing after a timed asynchronous render
+    ctx.set_timing(True)
+    ctx.render(out.data_ptr(), None, abi.Options.make(), None)
+    torch.cuda.synchronize()
+    with pytest.raises(device.RenderError, match="watchdog"):
+        ctx.read_timing()
+    ctx.set_timing(False)
+    # (4) ... and the synchronous form reports its own render
+    with pytest.raises(device.RenderError, match="watchdog"):
+        ctx.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
+    ctx.close()
+    # the one-shot call (what src/main.rs:57 would bind) is synchronous: same error code, no image handed over as OK
+    device.set_knob("spin_idle", 1)
+    try:
+        with pytest.raises(device.RenderError, match="watchdog"):
+            device.render(sc, sc.camera, sc.settings, abi.Options.make())
+    finally:
+        device.clear_knobs()
+    # a context with the product's limits renders the same image as before: the device is fine
+    again = fresh(0)
+    st2 = again.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
+    again.check()
+    again.close()
+    assert torch.equal(out, want) and st2.rays == st.rays

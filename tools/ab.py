@@ -11,7 +11,7 @@ VARIANTS = {   # name: (defines, flags)
 if os.environ.get("AB_VARIANTS"):
     import json; VARIANTS = {k: (tuple(v[0]), tuple(v[1])) for k, v in json.loads(os.environ["AB_VARIANTS"]).items()}
 ENVS = {}
-if os.environ.get("AB_ENVS"):        # {"name": {"lib": "<variant>", "env": {...}}}: same library, different set_scene-time env overrides
+if os.environ.get("AB_ENVS"):        # {"name": {"lib": "<variant>", "knobs": {"kernel": 7, ...}}}: same library, different diagnostic knobs (mi355rt_debug_set_knob)
     import json; ENVS = json.loads(os.environ["AB_ENVS"])
 WL = {"cornell": ("data/scenes/tungsten/cornell-box/scene.json", 800, 600, 256, 30, False),
       "semesterbild": ("data/scenes/semesterbild.json", 800, 600, 64, 30, False),
@@ -32,6 +32,7 @@ for v, (defs, flags) in VARIANTS.items():
     L.mi355rt_context_destroy.argtypes = [C.c_void_p]; L.mi355rt_last_error.restype = C.c_char_p
     L.mi355rt_context_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.mi355rt_context_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.mi355rt_debug_set_knob.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     libs[v] = L
 ALL_LIBS = dict(libs)
 for wl in names:
@@ -45,9 +46,9 @@ for wl in names:
         for n, spec in ENVS.items(): libs[n] = base_libs[spec["lib"]]
         times = {v: [] for v in libs}
     for v, L in libs.items():
-        for k in ("MI355RT_GUIDED_MULT", "MI355RT_TRAV_MIN", "MI355RT_KERNEL"): os.environ.pop(k, None)
-        if ENVS: os.environ.update(ENVS[v]["env"])
         h = C.c_void_p(); assert L.mi355rt_context_create(0, C.byref(h)) == 0, L.mi355rt_last_error()
+        if ENVS:
+            for k, val in ENVS[v].get("knobs", {}).items(): assert L.mi355rt_debug_set_knob(h, k.encode(), int(val)) == 0, L.mi355rt_last_error()
         assert L.mi355rt_context_set_scene(h, C.byref(sc.c), C.byref(sc.camera), C.byref(sc.settings)) == 0, L.mi355rt_last_error()
         ctxs[v] = h
     opt = abi.Options.make(strip_rows=5, n_parts=PARTS, part=0)

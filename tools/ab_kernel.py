@@ -1,4 +1,5 @@
-"""A/B of the counter-mode kernel variants / trav_min in one process (env overrides are read at set_scene)."""
+"""A/B of the counter-mode kernel variants / trav_min in one process, on the reference build (-DMI355RT_REFS: the product sources plus
+the retired state-machine and walk-pool kernels); variants are chosen with the diagnostic knobs of mi355rt_debug_set_knob."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import pkg
@@ -8,9 +9,10 @@ WL = {"cornell": ("data/scenes/tungsten/cornell-box/scene.json", 800, 600, 256, 
       "semesterbild": ("data/scenes/semesterbild.json", 800, 600, 64, 30, False),
       "veach": ("data/scenes/tungsten/veach-mis/scene.json", 1280, 720, 64, 16, False),
       "teapot": ("data/scenes/tungsten/teapot/scene.json", 800, 600, 64, 30, True)}
-SETTINGS = [("lockstep", {"MI355RT_KERNEL": "1"})] + [(f"sm{t}", {"MI355RT_KERNEL": "2", "MI355RT_TRAV_MIN": str(t)}) for t in (16, 24, 32)] \
-         + [("sm24i1", {"MI355RT_KERNEL": "2", "MI355RT_TRAV_MIN": "24", "MI355RT_INLINE_STEPS": "1"})]
-ENV_KEYS = ("MI355RT_KERNEL", "MI355RT_TRAV_MIN", "MI355RT_INLINE_STEPS", "MI355RT_WALKERS", "MI355RT_POOL_PATIENCE")
+SETTINGS = [("lockstep", {"kernel": "1"}), ("wavefront", {"kernel": "7"})] + [(f"sm{t}", {"kernel": "2", "trav_min": str(t)}) for t in (16, 24, 32)] \
+         + [("sm24i1", {"kernel": "2", "trav_min": "24", "inline_steps": "1"})]
+ENV_KEYS = ("kernel", "trav_min", "inline_steps", "walkers", "pool_patience")
+REFS = device.refs()
 if os.environ.get("AB_KERNEL_SETTINGS"):     # "name=KERNEL:TRAV_MIN[:INLINE_STEPS[:WALKERS[:PATIENCE]]],..."
     SETTINGS = [(kv.split("=")[0], dict(zip(ENV_KEYS, kv.split("=")[1].split(":")))) for kv in os.environ["AB_KERNEL_SETTINGS"].split(",")]
 for wl in sys.argv[1:] or ["semesterbild", "teapot"]:
@@ -20,9 +22,9 @@ for wl in sys.argv[1:] or ["semesterbild", "teapot"]:
     out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
     ctxs = {}
     for name, env in SETTINGS:
-        for k in ENV_KEYS: os.environ.pop(k, None)
-        os.environ.update(env)
-        c = device.Context(0); c.set_scene(sc, sc.camera, sc.settings); ctxs[name] = c
+        c = device.Context(0, REFS)
+        for k, val in env.items(): c.set_knob(k, int(val))
+        c.set_scene(sc, sc.camera, sc.settings); ctxs[name] = c
     times = {n: [] for n in ctxs}; info = {}
     for rnd in range(5):
         for n, c in ctxs.items():

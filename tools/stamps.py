@@ -27,7 +27,7 @@ for name, path, W, H, spp, depth, skip in [("cornell", "data/scenes/tungsten/cor
     blk = list(raw)[8:16]
     if sum(blk):
         rays = st.rays
-        wf = os.environ.get("MI355RT_KERNEL", "7") == "7" and name in ("semesterbild", "teapot")
+        wf = ctx.kernel_variant() == 7
         for i, n in enumerate(["WALK passes", "TOP1 passes", "(no TOP0 stage any more)", "SHADE+TOP0 passes"] if wf else ["inner-node steps", "leaf phases", "TOP passes", "SHADE passes"]):
             e, l = blk[2 * i], blk[2 * i + 1]
             if e: print(f"   {n:18s} executions per 64 rays {e / (rays / 64):7.2f}   mean lanes {l / e:5.1f}")

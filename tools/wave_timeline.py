@@ -4,7 +4,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from conftest import pkg
 build = pkg("build")
 os.environ["MI355RT_DEVICE_SO"] = build.build_device_variant("stamps", ["MI355RT_STAMPS"])
-os.environ["MI355RT_WAVE_TIMES"] = "1"
 import numpy as np, torch
 torch.zeros(1, device="cuda")
 host, device, abi = pkg("host"), pkg("device"), pkg("abi")
@@ -12,7 +11,7 @@ SCENES = {"cornell": ("data/scenes/tungsten/cornell-box/scene.json", 30, False),
           "teapot": ("data/scenes/tungsten/teapot/scene.json", 64, True)}
 path, depth, skip = SCENES[sys.argv[1] if len(sys.argv) > 1 else "cornell"]
 sc = host.LoadedScene(os.path.join(ROOT, path), 800, 600, 256, depth, skip_unknown_primitives=skip)
-ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings)
+ctx = device.Context(0); ctx.set_knob("wave_times", 1); ctx.set_scene(sc, sc.camera, sc.settings)
 out = torch.zeros(800 * 600, dtype=torch.int32, device="cuda")
 for parts in (1, 8):
     opt = abi.Options.make(strip_rows=5, n_parts=parts, part=0)
