@@ -89,8 +89,10 @@ def usable_cores():
     return n, why
 
 
-def load_pmc(workload, kernel_hash):
-    """Counters of the dominant kernel per STEP (all bands of one full render) for `workload`, or the reason there are none."""
+def load_pmc(workload, kernel_hash, kernel_name=None):
+    """Counters of the dominant kernel per STEP (all bands of one full render) for `workload`, or the reason there are none:
+    "absent", "unreadable", "stale" (taken on other kernel sources), "other-kernel" (taken while another kernel variant served the
+    workload), "partial" (a counter pass is missing: tools/pmc_collect.py leaves such workloads out, older files may not)."""
     if not os.path.exists(PMC_FILE):
         return None, "absent"
     try:
@@ -100,7 +102,13 @@ def load_pmc(workload, kernel_hash):
     if doc.get("kernel_hash") != kernel_hash:
         return None, "stale"
     rec = doc.get("workloads", {}).get(workload)
-    return (rec, "fresh") if rec else (None, "absent")
+    if not rec:
+        return None, "absent"
+    if kernel_name is not None and rec.get("kernel") != kernel_name:
+        return None, "other-kernel"
+    if not all(isinstance(rec.get(k), (int, float)) for k in ("valu_wave_insts_per_step", "hbm_bytes_per_step", "valu_lane_utilisation")):
+        return None, "partial"
+    return rec, "fresh"
 
 
 def main():
@@ -256,7 +264,7 @@ def main():
         resolve_ms_per_step = k_resolve_ms / max(args.steps, 1)
         share = local_samples / total_samples            # a rank renders its strips only; counters were taken on the whole image
         khash = build.kernel_hash()
-        pmc, pmc_state = load_pmc(args.workload, khash)
+        pmc, pmc_state = load_pmc(args.workload, khash, KERNEL_NAMES.get(variant))
         peak_inst = VALU_SIMDS * VALU_CLOCK_HZ / VALU_CYCLES_PER_WAVE64_INST
         achieved = frac = lane_util = traffic = insts = None
         hbm = None

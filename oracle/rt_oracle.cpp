@@ -62,7 +62,7 @@ inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }   
 inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }         // vec3.rs:95-104
 inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }            // vec3.rs:106-115
 inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }                              // vec3.rs:143-152
-inline V3 divf(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }                 // vec3.rs:117-129 (panic for |s|<1e-4 not modelled)
+inline V3 divf(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }                 // vec3.rs:117-129; its panic for |s| < 1e-4 is reached only through sphere.rs:38: build_scene() refuses such a sphere
 inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }            // vec3.rs:17-19
 inline V3 cross(V3 a, V3 b) {                                                         // vec3.rs:21-27
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
@@ -571,6 +571,9 @@ bool build_scene(const mi355rt_scene* in, Scene& sc) {
         if (p.kind >= MI355RT_PRIM_KIND_COUNT) return false;
         if (p.material >= sc.mats.size()) return false;
         if (p.kind == MI355RT_PRIM_MESH && p.mesh >= sc.meshes.size()) return false;
+        // sphere.rs:38 divides by the radius with `Vec3 / f32`, which PANICS for |radius| < 1e-4 (vec3.rs:120-122) the first time such
+        // a sphere is hit: the reference cannot render the scene, so neither side accepts it (the HIP path returns MI355RT_ERR_INVALID).
+        if (p.kind == MI355RT_PRIM_SPHERE && std::fabs(p.data[3]) < 1e-4f) return false;
     }
     for (const auto& m : sc.mats) if (m.kind >= MI355RT_MAT_KIND_COUNT) return false;
     return true;

@@ -505,8 +505,10 @@ def load_scene(json_path, width=0, height=0, spp=0, max_depth=0, skip_unknown_pr
     if res is not None:
         if _is_num(res):
             w = h = int(res)
-        else:
+        elif isinstance(res, list) and len(res) == 2:       # ResolutionConfig::Explicit([usize; 2]), parser.rs:69-72
             w, h = int(res[0]), int(res[1])
+        else:
+            raise ValueError("camera.resolution: data did not match any variant of untagged enum ResolutionConfig")
     if cfg.get("renderer") and cfg["renderer"].get("spp") is not None:
         s_pp = int(cfg["renderer"]["spp"])
     if cfg.get("integrator") and cfg["integrator"].get("max_bounces") is not None:

@@ -15,6 +15,8 @@
 #include <limits>
 #include <string>
 #include <stdexcept>
+#include <system_error>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -37,12 +39,25 @@ struct Builder {
     uint32_t* leaf_indices = nullptr;          // preallocated: n
     std::atomic<uint32_t> max_depth{0};
     std::atomic<int> spare_threads{0};         // threads that may still be started
+    std::atomic<bool> worker_failed{false};    // a helper thread's build threw (allocation in the sort): reported by the caller, never thrown across a thread boundary
+    // Node count of the subtree over n triangles at `depth`.  Halving yields at most two distinct sizes per level, so the table
+    // filled by the first call (before any helper thread exists) has ~2 x depth entries and is read-only afterwards.
+    std::unordered_map<uint64_t, uint32_t> sizes;
 
     static constexpr size_t MAX_DEPTH = 25, MIN_TRIANGLES_PER_LEAF = 4;
-    static uint32_t subtree_nodes(size_t n, uint32_t depth) {
+    uint32_t fill_sizes(size_t n, uint32_t depth) {
         if (n <= MIN_TRIANGLES_PER_LEAF || depth >= MAX_DEPTH) return 1u;
+        const uint64_t key = ((uint64_t)n << 8) | depth;
+        auto it = sizes.find(key);
+        if (it != sizes.end()) return it->second;
         const size_t mid = n / 2;
-        return 1u + subtree_nodes(mid, depth + 1) + subtree_nodes(n - mid, depth + 1);
+        const uint32_t v = 1u + fill_sizes(mid, depth + 1) + fill_sizes(n - mid, depth + 1);
+        sizes.emplace(key, v);
+        return v;
+    }
+    uint32_t subtree_nodes(size_t n, uint32_t depth) const {
+        if (n <= MIN_TRIANGLES_PER_LEAF || depth >= MAX_DEPTH) return 1u;
+        return sizes.at(((uint64_t)n << 8) | depth);
     }
     static float centroid_axis(const mi355rt_triangle& t, int axis) {
         float s = (t.v0[axis] + t.v1[axis]) + t.v2[axis];
@@ -75,13 +90,26 @@ struct Builder {
         const uint32_t l = slot + 1u, r = l + subtree_nodes(mid, depth + 1);
         node.left = l; node.right = r; node.first_index = 0; node.index_count = 0;
         // the right half on another thread while one is free and the job is worth it, the left half here
-        if (n >= 2048 && spare_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
-            std::thread other([=] { build(idx + mid, n - mid, depth + 1, r, index_offset + (uint32_t)mid); });
-            build(idx, mid, depth + 1, l, index_offset);
-            other.join();
-            spare_threads.fetch_add(1, std::memory_order_relaxed);
-        } else {
-            if (n >= 2048) spare_threads.fetch_add(1, std::memory_order_relaxed);   // undo the reservation that failed
+        bool reserved = n >= 2048 && spare_threads.fetch_sub(1, std::memory_order_relaxed) > 0;
+        if (n >= 2048 && !reserved) spare_threads.fetch_add(1, std::memory_order_relaxed);   // undo the reservation that failed
+        if (reserved) {
+            std::thread other;
+            try {
+                // nothing may leave the helper's thread function (it would be std::terminate): a throw inside is recorded instead
+                other = std::thread([=] { try { build(idx + mid, n - mid, depth + 1, r, index_offset + (uint32_t)mid); }
+                                          catch (...) { worker_failed.store(true, std::memory_order_relaxed); } });
+            } catch (const std::system_error&) {                  // no thread to be had (EAGAIN under a process / thread limit): build inline
+                spare_threads.fetch_add(1, std::memory_order_relaxed);
+                reserved = false;
+            }
+            if (reserved) {
+                try { build(idx, mid, depth + 1, l, index_offset); }
+                catch (...) { other.join(); spare_threads.fetch_add(1, std::memory_order_relaxed); throw; }
+                other.join();
+                spare_threads.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
+        if (!reserved) {
             build(idx, mid, depth + 1, l, index_offset);
             build(idx + mid, n - mid, depth + 1, r, index_offset + (uint32_t)mid);
         }
@@ -103,10 +131,12 @@ int bvh_build_threads(const mi355rt_triangle* tris, uint32_t n, std::vector<mi35
     if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads <= 0) n_threads = 1; if (n_threads > 16) n_threads = 16; }
     std::vector<uint32_t> idx(n);
     for (uint32_t i = 0; i < n; ++i) idx[i] = i;          // mesh_object.rs:44
-    nodes.assign(Builder::subtree_nodes(n, 0), mi355rt_bvh_node{});
+    Builder b;
+    nodes.assign(b.fill_sizes(n, 0), mi355rt_bvh_node{});
     indices.assign(n, 0u);
-    Builder b; b.tris = tris; b.nodes = nodes.data(); b.leaf_indices = indices.data(); b.spare_threads.store(n_threads - 1);
+    b.tris = tris; b.nodes = nodes.data(); b.leaf_indices = indices.data(); b.spare_threads.store(n_threads - 1);
     b.build(idx.data(), n, 0, 0u, 0u);
+    if (b.worker_failed.load()) return set_error(MI355RT_ERR_OOM, "bvh_build: a helper thread ran out of memory");
     max_depth = b.max_depth.load();
     return MI355RT_OK;
 }

@@ -28,15 +28,15 @@ static bool make_triangle(V3 v0, V3 v1, V3 v2, mi355rt_triangle& out) {
 
 // Malformed input fails the whole mesh, as `tobj::load_obj(..)?` does (mesh_object.rs:64): a `v` line without three
 // floats (tobj PositionParseError), a face corner that is not an integer (FaceParseError) or that points outside the
-// vertices read so far (FaceVertexOutOfBounds), an index stream that is not a multiple of 3 after triangulation --
-// points and lines stay 1 / 2 indices -- (mesh_object.rs:98-104), and a file without any face (:67-69).
+// vertices read so far (FaceVertexOutOfBounds), and a file without any face (:67-69).  (mesh_object.rs:98-104's "index count
+// not a multiple of 3" cannot occur: with triangulate + ignore_points + ignore_lines every face tobj keeps is triangles.)
 int load_obj(const std::string& path, std::vector<mi355rt_triangle>& tris) {
     std::ifstream f(path);
     if (!f) return set_error(MI355RT_ERR_IO, "cannot open OBJ " + path);
     std::vector<V3> verts;
     std::vector<long> face;
     std::string line;
-    size_t line_no = 0, n_faces = 0, n_indices = 0;
+    size_t line_no = 0, n_faces = 0;
     auto at = [&](const char* what) { return set_error(MI355RT_ERR_IO, std::string("OBJ ") + path + ":" + std::to_string(line_no) + ": " + what); };
     while (std::getline(f, line)) {
         ++line_no;
@@ -59,8 +59,10 @@ int load_obj(const std::string& path, std::vector<mi355rt_triangle>& tris) {
                 face.push_back(v);
             }
             if (face.empty()) return at("face without corners");
+            // tobj 4.0.3 GPU_LOAD_OPTIONS = triangulate + single_index + ignore_points + ignore_lines (mesh_object.rs:64): an `f`
+            // with one or two corners is validated like any other and then dropped -- it never reaches mesh.indices, so it can
+            // neither add a triangle nor break the "multiple of 3" check of mesh_object.rs:98-104.  The model still exists.
             ++n_faces;
-            n_indices += face.size() >= 3 ? 3 * (face.size() - 2) : face.size();
             for (size_t k = 1; k + 1 < face.size(); ++k) {
                 mi355rt_triangle t;
                 if (make_triangle(verts[face[0]], verts[face[k]], verts[face[k + 1]], t)) tris.push_back(t);
@@ -68,7 +70,6 @@ int load_obj(const std::string& path, std::vector<mi355rt_triangle>& tris) {
         }
     }
     if (n_faces == 0) return set_error(MI355RT_ERR_IO, "No models found in OBJ file: " + path);
-    if (n_indices % 3 != 0) return set_error(MI355RT_ERR_IO, "Invalid index data length in OBJ file: " + path);
     return MI355RT_OK;
 }
 

@@ -218,9 +218,9 @@ void load_impl(const std::string& json_path, const mi355rt_load_overrides* ov, m
     if (!cam || !cam->is_object()) bad("missing field `camera`");
     if (const JsonValue* res = cam->opt("resolution")) {
         if (res->is_number()) width = height = num_usize(*res, "camera.resolution");                    // ResolutionConfig::Square
-        else if (res->is_array()) {                                                                       // ::Explicit(Vec<usize>): any length parses,
-            std::vector<uint32_t> a; for (const JsonValue& e : res->arr) a.push_back(num_usize(e, "camera.resolution[]"));
-            if (a.size() == 2) { width = a[0]; height = a[1]; }                                           // only len 2 is used (parser.rs:266-271)
+        else if (res->is_array() && res->arr.size() == 2) {                                              // ::Explicit([usize; 2]), parser.rs:69-72: serde accepts
+            width = num_usize(res->arr[0], "camera.resolution[]");                                        // exactly two elements -- any other length
+            height = num_usize(res->arr[1], "camera.resolution[]");                                       // matches no variant and fails the whole load
         } else bad("camera.resolution: data did not match any variant of untagged enum ResolutionConfig");
     }
     if (const JsonValue* r = cfg.opt("renderer")) if (const JsonValue* s = r->opt("spp")) spp = num_usize(*s, "renderer.spp");

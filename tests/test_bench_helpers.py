@@ -33,6 +33,13 @@ def test_stale_or_missing_counters_are_reported_not_used(tmp_path, monkeypatch):
     assert bench.load_pmc("cornell-box-800x600x256-d30", "abc") == (None, "stale")
     p.write_text(json.dumps({"kernel_hash": "abc", "workloads": {}}))
     assert bench.load_pmc("cornell-box-800x600x256-d30", "abc") == (None, "absent")
+    good = {"kernel": "k_render_ctr_simple", "valu_wave_insts_per_step": 1.0, "hbm_bytes_per_step": 2.0, "valu_lane_utilisation": 0.5}
+    p.write_text(json.dumps({"kernel_hash": "abc", "workloads": {"cornell-box-800x600x256-d30": good}}))
+    assert bench.load_pmc("cornell-box-800x600x256-d30", "abc", "k_render_ctr_simple") == (good, "fresh")
+    assert bench.load_pmc("cornell-box-800x600x256-d30", "abc", "k_render_ctr_nomesh") == (None, "other-kernel")   # counters of one variant, time of another
+    part = {k: v for k, v in good.items() if k != "hbm_bytes_per_step"}                                              # a counter pass failed
+    p.write_text(json.dumps({"kernel_hash": "abc", "workloads": {"cornell-box-800x600x256-d30": part}}))
+    assert bench.load_pmc("cornell-box-800x600x256-d30", "abc", "k_render_ctr_simple") == (None, "partial")
     p.write_text("{not json")
     assert bench.load_pmc("cornell-box-800x600x256-d30", "abc") == (None, "unreadable")
 

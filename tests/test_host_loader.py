@@ -174,3 +174,47 @@ def test_exr_writer_roundtrip(native, tmp_path):
     host.write_exr(path, img, 13, 7)
     got = _read_exr(open(path, "rb").read())
     assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
+
+
+def _mini_scene(tmp_path, camera_extra=None, prims=None, name="s.json"):
+    cam = {"transform": {"position": [0, 0, 5], "look_at": {"x": 0, "y": 0, "z": 0}, "up": [0, 1, 0]}, "fov": 40}
+    cam.update(camera_extra or {})
+    p = tmp_path / name
+    p.write_text(json.dumps({"camera": cam, "primitives": prims or [], "bsdfs": [{"name": "m", "type": "lambert", "albedo": 0.5}]}))
+    return str(p)
+
+
+@pytest.mark.parametrize("res,ok", [([320, 200], True), (64, True), ([320], False), ([320, 200, 3], False), ([], False), ("320x200", False)])
+def test_resolution_is_a_number_or_exactly_two_numbers(res, ok, native, tmp_path):
+    """ResolutionConfig is `Square(usize) | Explicit([usize; 2])`, untagged (/root/reference/src/tungsten/parser.rs:66-72): serde takes
+    an array of exactly two -- any other length matches no variant and the whole scene fails to load."""
+    host, _ = native
+    from oracle import scene_loader
+    path = _mini_scene(tmp_path, {"resolution": res})
+    if ok:
+        want = (res, res) if isinstance(res, int) else tuple(res)
+        a, b = host.LoadedScene(path), scene_loader.load_scene(path)
+        assert (a.settings.width, a.settings.height) == want == (b.settings.width, b.settings.height)
+    else:
+        with pytest.raises(RuntimeError, match="did not match any variant of untagged enum ResolutionConfig"):
+            host.LoadedScene(path)
+        with pytest.raises(ValueError, match="ResolutionConfig"):
+            scene_loader.load_scene(path)
+
+
+def test_obj_points_and_lines_are_dropped_like_tobj_does(native, abi, tmp_path):
+    """tobj 4.0.3 GPU_LOAD_OPTIONS has ignore_points and ignore_lines set (/root/reference/src/mesh/mesh_object.rs:64): an `f` with
+    one or two corners never reaches mesh.indices.  The mesh keeps its triangles (it does not vanish with "Invalid index data
+    length"); a short face whose corner is out of range still fails the mesh, as tobj's parser does."""
+    host, _ = native
+    from oracle import scene_loader
+    (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf 1 2\nf 1 2 3\nf 4\nf 2 4 3\nf 3 1\n")
+    prims = [{"type": "mesh", "file": "m.obj", "bsdf": "m", "transform": {}}]
+    path = _mini_scene(tmp_path, prims=prims)
+    a, b = host.LoadedScene(path), scene_loader.load_scene(path)
+    assert a.c.n_meshes == 1 and a.c.n_triangles == 2 == b.c.n_triangles
+    assert np.array_equal(_bytes(a.c.triangles, 2, abi.Triangle), _bytes(b.c.triangles, 2, abi.Triangle))
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\nf 1 9\n")
+    bad = _mini_scene(tmp_path, prims=[{"type": "mesh", "file": "bad.obj", "bsdf": "m", "transform": {}}], name="bad.json")
+    c = host.LoadedScene(bad)                                   # the mesh fails to load and is skipped with a warning (parser.rs:690-700); the scene loads
+    assert c.c.n_meshes == 0 and c.c.n_primitives == 0

@@ -57,6 +57,41 @@ def test_sphere_outside_inside_and_grazing(oracle_mod, abi):
     assert not hit
 
 
+def _tiny_sphere_scene(abi, radius):
+    sc = _scene(abi, [_prim(abi, abi.PRIM_SPHERE, [0, 0, 0, 1]), _prim(abi, abi.PRIM_SPHERE, [0, 2, 0, radius])])
+    cam = abi.Camera(); cam.position[:] = [0, 0, 8]; cam.forward[:] = [0, 0, -1]; cam.right[:] = [1, 0, 0]; cam.true_up[:] = [0, 1, 0]
+    cam.half_width, cam.half_height = 0.4, 0.3
+    return sc, cam, abi.Settings(8, 6, 1, 2)
+
+
+@pytest.mark.parametrize("radius", [0.0, 9.9e-5, -5e-5])
+def test_a_sphere_the_reference_panics_on_is_refused_by_the_oracle(radius, oracle_mod, abi):
+    """sphere.rs:38 computes the normal as `(position - center) / radius` with Vec3's `/ f32`, which panics for |radius| < 1e-4
+    (/root/reference/src/vec3.rs:120-122): the reference cannot render such a scene, so the oracle does not either."""
+    sc, cam, st = _tiny_sphere_scene(abi, radius)
+    with pytest.raises(RuntimeError, match="oracle_render failed: -1"):
+        oracle_mod.render(sc, cam, st, abi.Options.make())
+    ok, cam, st = _tiny_sphere_scene(abi, 1e-4)                              # exactly EPSILON: `abs() < EPSILON` is false, it renders
+    oracle_mod.render(ok, cam, st, abi.Options.make())
+    neg, cam, st = _tiny_sphere_scene(abi, -0.5)                             # a negative radius of ordinary size is the reference's business: allowed
+    oracle_mod.render(neg, cam, st, abi.Options.make())
+
+
+@pytest.mark.gpu
+def test_hip_path_refuses_the_sphere_the_reference_panics_on(native, oracle_mod, abi):
+    _, device = native
+    for radius in (0.0, 9.9e-5, -5e-5):
+        sc, cam, st = _tiny_sphere_scene(abi, radius)
+        with pytest.raises(device.RenderError, match="sphere radius") as e:
+            device.render(sc, cam, st, abi.Options.make())
+        assert e.value.rc == abi.ERR_INVALID
+    for radius in (1e-4, -0.5):                                             # what the reference renders, both sides render alike
+        sc, cam, st = _tiny_sphere_scene(abi, radius)
+        gp, gl, gs = device.render(sc, cam, st, abi.Options.make())
+        op, ol, cnt = oracle_mod.render(sc, cam, st, abi.Options.make())
+        assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op) and gs.rays == cnt.rays
+
+
 def test_quad_edges_use_epsilon_inclusive_bounds(oracle_mod, abi):
     sc = _scene(abi, [_quad_xz(abi, 0.0)])
     assert oracle_mod.scene_hit(sc, (0.25, 1, 0.25), (0, -1, 0))[0]

@@ -72,8 +72,10 @@ def main():
     doc = {"kernel_hash": build.kernel_hash(), "collected_unix": int(time.time()),
            "command": "rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --workload <W>",
            "groups": GROUPS, "per": "step (one full render of the workload = all workspace bands)", "workloads": {}}
+    failed = []
     for wl in args.workloads:
         wdir = os.path.join(args.out, wl)
+        ok = True
         for i, grp in enumerate(GROUPS):
             pdir = os.path.join(wdir, f"pass{i}")
             cmd = ["timeout", "-k", "10", str(args.pass_timeout), "rocprofv3", "--pmc", *grp, "--output-format", "csv", "-d", pdir, "--",
@@ -86,9 +88,20 @@ def main():
                 print("a pass hit its time limit: stopping (no further GPU work after a kill)", flush=True)
                 json.dump(doc, open(os.path.join(args.out, "pmc_counters.partial.json"), "w"), indent=1)
                 sys.exit(1)
+            if rc != 0:                       # an unsupported counter, a failing bench run, ...: this workload gets NO record
+                print(f"{wl}: pass {i} failed (exit {rc}, see {wl}.pass{i}.log): the workload is left out of pmc_counters.json", flush=True)
+                ok = False
+                break
+        if not ok:
+            failed.append(wl)
+            continue
         s = summarize(wdir)
         r = s.get("k_render_ctr", {})
         rec = {"raw": s}
+        if not all(c in r for grp in GROUPS for c in grp):      # every pass ran, but a counter is missing from its CSV
+            print(f"{wl}: counters missing from the CSVs {[c for grp in GROUPS for c in grp if c not in r]}: left out", flush=True)
+            failed.append(wl)
+            continue
         if "SQ_INSTS_VALU" in r:
             rec["kernel"] = r["_kernel"]
             rec["valu_wave_insts_per_step"] = r["SQ_INSTS_VALU"]
@@ -104,6 +117,9 @@ def main():
         doc["workloads"][wl] = rec
         json.dump(doc, open(os.path.join(args.out, "pmc_counters.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({w: {k: v for k, v in r.items() if k != "raw"} for w, r in doc["workloads"].items()}, indent=1))
+    if failed:
+        print(f"workloads without counters: {failed}", flush=True)
+        sys.exit(2)
 
 
 if __name__ == "__main__":
