@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
       mi355rt_loaded_scene* ls = nullptr; expect(mi355rt_scene_load_json((tmp + "/spp.json").c_str(), nullptr, &ls) != MI355RT_OK, "spp 2.5 should be refused"); if (ls) mi355rt_scene_free(ls); }
     put(tmp + "/ok_empty.json", scene_with("")); load(tmp + "/ok_empty.json", true);
     put(tmp + "/res3.json", [&] { std::string s = scene_with(""); const std::string from = "\"resolution\":[8,8]"; s.replace(s.find(from), from.size(), "\"resolution\":[1,2,3]"); return s; }());
-    load(tmp + "/res3.json", true);                                            // Explicit(Vec<usize>) of length 3 parses and is ignored (parser.rs:266-271)
+    load(tmp + "/res3.json", false);                                           // Explicit([usize; 2]), parser.rs:69-72: three elements match no variant of the untagged enum
 
     // ---- OBJ ----
     struct Case { const char* name; std::string body; bool ok; };
