@@ -566,8 +566,8 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         HIP_TRY(hipMemcpyAsync(ctx->rows.p, ctx->rows_host.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         ctx->rows_valid = true;
     }
-    if ((rc = ctx->stats.ensure(16))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, 16 * sizeof(unsigned long long), stream));
+    if ((rc = ctx->stats.ensure(STATS_WORDS))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, STATS_WORDS * sizeof(unsigned long long), stream));
 
     double render_ms = 0, resolve_ms = 0, total_ms = 0;
     uint32_t n_bands = 0, grid_blocks = 0, block_threads = 0;
@@ -598,7 +598,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         const uint64_t spp = s1 - s0;                                 // samples per pixel in THIS launch
         const uint64_t total_pixels = (uint64_t)n_rows * st.width;
         uint64_t ws_cap = (opt && opt->workspace_bytes) ? opt->workspace_bytes : (32ull << 30);   // 288 GB of HBM: default = the 2^31-sample band limit; only what a band needs is allocated
-        uint64_t max_samples = std::min<uint64_t>(ws_cap / 12, (1ull << 31) - 2 * BATCH_MAX);
+        uint64_t max_samples = std::min<uint64_t>(ws_cap / 12, (1ull << 31) - 16 * RUN_LIMIT);     // the shard counters overshoot by at most one run per claiming wave's last try; 32-bit headroom
         if (max_samples < spp) return fail(MI355RT_ERR_INVALID, "workspace_bytes too small for one pixel (needs spp * 12 bytes)");
         uint64_t band_pixels_max = std::min<uint64_t>(max_samples / spp, total_pixels);
         // Only what a band needs is allocated.  When even that does not fit (another tenant on the GPU, a small device),
@@ -625,7 +625,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.sample0 = s0;
         magic_div((uint32_t)spp, p.spp_mul, p.spp_shift); magic_div(st.width, p.width_mul, p.width_shift);
         p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;
-        p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, pool ? POOL_NODE_CAP : LDS_NODE_CAP);
+        p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, pool ? POOL_NODE_CAP : LDS_NODE_CAP);    // (the wavefront kernel clamps to its own WF_LDS_NODES)
         p.walker_waves = ctx->walker_waves; p.pool_patience = ctx->pool_patience;
         p.err = ctx->errword.p; p.spin_limit_idle = ctx->spin_limit_idle; p.spin_limit_entry = ctx->spin_limit_entry;
         ResolveParams r{};
@@ -640,9 +640,12 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             const uint64_t np = std::min<uint64_t>(band_pixels_max, total_pixels - p0);
             p.band_pixel0 = (uint32_t)p0; p.band_samples = (uint32_t)(np * spp);
             p.batch_counter = ctx->counters.p + (size_t)b * ctr_words;
+            const bool wf = variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB;
+            const uint32_t run_min = wf ? RUN_WAVEFRONT_MIN : BATCH_MIN, run_max = wf ? RUN_WAVEFRONT : BATCH_MAX;   // what the kernel's WorkCursorT is compiled with
             p.shard_samples = (p.band_samples + WORK_SHARDS - 1) / WORK_SHARDS;
+            p.shard_samples = (p.shard_samples + run_max - 1) / run_max * run_max;           // shards begin on run boundaries (fixed runs then stay aligned)
             const uint32_t waves_per_block = block_threads / 64;
-            const uint32_t min_runs = (p.band_samples + BATCH_MIN - 1) / BATCH_MIN;           // never more waves than minimum-size runs
+            const uint32_t min_runs = (p.band_samples + run_min - 1) / run_min;               // never more waves than minimum-size runs
             const uint32_t grid = std::max(1u, std::min(resident, (min_runs + waves_per_block - 1) / waves_per_block));
             const uint32_t claiming_waves = pool ? waves_per_block - ctx->walker_waves : waves_per_block;   // (the wavefront kernel: every wave claims)     // walker waves never claim samples
             p.guided_div = std::max(1u, ctx->guided_mult * grid * claiming_waves / WORK_SHARDS);
@@ -710,11 +713,11 @@ int mi355rt_debug_kernel_variant(mi355rt_context* ctx, uint32_t* out) {
     return MI355RT_OK;
 }
 
-// Diagnostic hook (not part of the public header): the 16 raw device counters of the last render.
-int mi355rt_debug_read_counters(mi355rt_context* ctx, unsigned long long* out16) {
-    if (!ctx || !out16 || !ctx->stats.p) return fail(MI355RT_ERR_INVALID, "no counters");
+// Diagnostic hook (not part of the public header): the STATS_WORDS (32) raw device counters of the last render.
+int mi355rt_debug_read_counters(mi355rt_context* ctx, unsigned long long* out32) {
+    if (!ctx || !out32 || !ctx->stats.p) return fail(MI355RT_ERR_INVALID, "no counters");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpy(out16, ctx->stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out32, ctx->stats.p, STATS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MI355RT_OK;
 }
 

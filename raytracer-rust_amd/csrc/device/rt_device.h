@@ -68,6 +68,17 @@ struct DevCamera { float position[3], forward[3], right[3], true_up[3], half_wid
 // 256 = one pixel's samples at the headline 256 spp: the lanes of a wave then share the camera ray and the first
 // hit, so whole accept blocks are skipped wave-wide (measured: 2048 -> 27.1 ms, 512 -> 26.1, 256 -> 25.8 on cornell).
 constexpr uint32_t BATCH_MIN = MI355RT_BATCH_MIN, BATCH_MAX = MI355RT_BATCH_MAX;   // paths a wave claims per global atomic (guided self-scheduling)
+// The wavefront kernel claims runs of a FIXED 256 samples, aligned to 256 within the band: at the headline 256 spp a run is exactly
+// one pixel, at 64 spp four whole pixels, at 4096 spp a sixteenth of one -- the rays a workgroup holds stay coherent, its passes
+// less divergent.  Measured (profiles/r03_ab_wavefront_run_length.txt, 800x600x256): [128, 256] guided 28.96 / 17.76 ms
+// (semesterbild / teapot), fixed 256 28.63 / 17.34, fixed 512 28.95 / 17.30, [256, 512] 29.31 / 17.62, fixed 1024 30.5 / 17.4.
+#ifndef MI355RT_RUN_WAVEFRONT
+#define MI355RT_RUN_WAVEFRONT 256
+#endif
+#ifndef MI355RT_RUN_WAVEFRONT_MIN
+#define MI355RT_RUN_WAVEFRONT_MIN MI355RT_RUN_WAVEFRONT     // < RUN_WAVEFRONT: guided shrinking at the end of a shard (see guided_mult_wf in rt_api.cpp)
+#endif
+constexpr uint32_t RUN_WAVEFRONT = MI355RT_RUN_WAVEFRONT, RUN_WAVEFRONT_MIN = MI355RT_RUN_WAVEFRONT_MIN, RUN_LIMIT = 2048;
 constexpr uint32_t BLOCK_THREADS = 256;         // lockstep kernels
 constexpr uint32_t BLOCK_THREADS_SM = 1024;     // state-machine kernels: 16 waves = 4 per SIMD = one workgroup per CU, sharing the LDS node copy
 constexpr uint32_t WORK_SHARDS = 8;            // one work counter per XCD (power of two)
@@ -91,8 +102,8 @@ struct RenderParams {
     uint32_t width, height, spp, max_depth;
     uint32_t band_pixel0;        // first local pixel (row-major over the selected rows) of this band
     uint32_t band_samples;       // band pixels * spp  (< 2^31)
-    uint32_t guided_div;         // run length = (left in the shard) / guided_div
-    uint32_t shard_samples;      // samples per shard: ceil(band_samples / WORK_SHARDS)
+    uint32_t guided_div;         // run length = (left in the shard) / guided_div, clamped to the kernel's [RMIN, RMAX] (WorkCursorT)
+    uint32_t shard_samples;      // samples per shard: ceil(band_samples / WORK_SHARDS), rounded up to a multiple of the kernel's longest run
     uint32_t seed_lo, seed_hi;
     uint32_t sample0;            // index of the first sample of this launch within its pixel (progressive rendering; 0 otherwise)
     uint32_t spp_mul, spp_shift, width_mul, width_shift;   // magic pairs for n / spp and n / width (n < 2^31)
@@ -165,6 +176,33 @@ bool render_ctr_variant_built(uint32_t variant);   // false for the retired mesh
 #define MI355RT_WF_THREADS 768
 #endif
 constexpr uint32_t BLOCK_THREADS_WF = MI355RT_WF_THREADS;   // wavefront kernel: waves per workgroup x 64 (A/B: fewer waves = more path slots per lane)
+// Wavefront kernel, LDS budget of one workgroup (rt_wavefront.h): control words, one ring per queue, the path slots, and -- in what is
+// left -- a copy of the first WF_LDS_NODES nodes of the (top-levels-first) node array.
+#ifndef MI355RT_WF_PATHS
+#define MI355RT_WF_PATHS 832                                // what fits beside seven rings (768 beside the eight there were: semesterbild +2.4 %, teapot +1.6 %)
+#endif
+#ifndef MI355RT_WF_RING
+#define MI355RT_WF_RING 1024
+#endif
+#ifndef MI355RT_WF_WGS_PER_CU
+#define MI355RT_WF_WGS_PER_CU 2
+#endif
+#ifndef MI355RT_WF_SLOT_WORDS
+#define MI355RT_WF_SLOT_WORDS 20
+#endif
+constexpr uint32_t WF_PATHS = MI355RT_WF_PATHS, WF_SLOT_WORDS = MI355RT_WF_SLOT_WORDS, WF_RING = MI355RT_WF_RING, WF_QUEUES = 7, WF_CTRL_WORDS = 32;
+constexpr uint32_t WF_FIXED_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
+constexpr uint32_t WF_LDS_BUDGET_WORDS = 163840u / 4u / MI355RT_WF_WGS_PER_CU;
+static_assert(WF_FIXED_WORDS <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budget");
+// Measured (profiles/r03_ab_wavefront_lds_nodes.txt): the copy buys nothing -- 348 nodes beside 704 slots, or 2 110 nodes with one
+// 16-wave workgroup per CU, run exactly as fast as the same geometry without the copy (the walk is bound by instruction issue at
+// low lane utilisation, not by node latency), and every slot given up for nodes costs time.  Default: no copy; -1 = fill the budget.
+#ifndef MI355RT_WF_LDS_NODES
+#define MI355RT_WF_LDS_NODES 0
+#endif
+constexpr uint32_t WF_LDS_NODES = MI355RT_WF_LDS_NODES >= 0 ? (uint32_t)MI355RT_WF_LDS_NODES : (WF_LDS_BUDGET_WORDS - WF_FIXED_WORDS) / 8u;    // 32-byte nodes
+static_assert(WF_FIXED_WORDS + 8u * WF_LDS_NODES <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budget (node copy)");
+constexpr uint32_t STATS_WORDS = 32;                         // u64 device counters per render: [0] paths, [1] rays, the rest diagnostic builds only
 inline uint32_t block_threads_of(uint32_t variant) { return variant >= 7u ? BLOCK_THREADS_WF : (variant == 2u || variant >= 4u) ? BLOCK_THREADS_SM : BLOCK_THREADS; }   // KERNEL_WAVEFRONT*, KERNEL_STATE_MACHINE* / KERNEL_POOL*
 
 }  // namespace mi355rt

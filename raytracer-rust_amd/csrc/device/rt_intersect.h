@@ -200,14 +200,19 @@ DI void mesh_setup(PrimPtr pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {   /
 // USE_LDS: nodes below `lds_count` are read from the workgroup's LDS copy (ds_read_b128), the rest from global memory.
 typedef float lds_v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) lds_v4f* lds_nodes_t;
-template <bool FIXED_AABB = false, bool USE_LDS = false>
-DI void mesh_step(const float4* __restrict__ n4, lds_nodes_t lds, uint32_t lds_count, float t_min, MeshTrav& m) {
+// USE_LDS: 0 = global memory only; 1 = the LDS copy when EVERY lane of the wave is below `lds_count` (wave-uniform choice);
+//          2 = chosen per lane (both loads may be in flight: LDS readers then also wait for the slowest global load of the wave).
+// SPEC (wavefront kernel's WALK stage): the walk does not stop at a hit leaf.  The leaf is left pending (leaf_a / leaf_b, and
+// `resume` = the node behind it) and the walk goes on with the unchanged best_t; a SECOND leaf while one is pending stalls the lane
+// in front of that leaf's node (it is visited again after the leaf phase).  See rt_wavefront.h for why this is exact.
+template <bool FIXED_AABB = false, int USE_LDS = 0, bool SPEC = false>
+DI void mesh_step(const float4* __restrict__ n4, lds_nodes_t lds, uint32_t lds_count, float t_min, MeshTrav& m, uint32_t* resume = nullptr, bool* stalled = nullptr) {
     // 32-bit byte offset from the uniform base: the load takes the base from SGPRs instead of a 64-bit per-lane address
     // The choice between the LDS copy and global memory is made for the WAVE (the LDS copy is a copy: global memory holds every
     // node): a per-lane choice would make the LDS readers wait for the other lanes' global loads (both paths fill the
     // same registers) and serialise the two latencies.  Whole array in LDS (semesterbild): always the LDS path.
     float4 q0, q1;
-    if (USE_LDS && __ballot(m.node >= lds_count) == 0ull) {
+    if (USE_LDS != 0 && (USE_LDS == 2 ? (m.node < lds_count) : (__ballot(m.node >= lds_count) == 0ull))) {
         lds_nodes_t lq = reinterpret_cast<lds_nodes_t>(reinterpret_cast<const __attribute__((address_space(3))) char*>(lds) + (m.node << 5));
         const lds_v4f l0 = lq[0], l1 = lq[1];
         q0 = make_float4(l0.x, l0.y, l0.z, l0.w); q1 = make_float4(l1.x, l1.y, l1.z, l1.w);
@@ -230,10 +235,20 @@ DI void mesh_step(const float4* __restrict__ n4, lds_nodes_t lds, uint32_t lds_c
     // Branch-free successor: hit inner node -> its left child `a`; missed node or leaf -> the escape link (a hit leaf's
     // triangles are tested first: leaf_b > 0 holds the walk until mesh_leaf() has run).
     const uint32_t count = b >> NODE_LINK_BITS, esc = b & NODE_END;
-    const bool take_leaf = ok && count != 0u;
-    m.node = (ok && count == 0u) ? a : esc;
-    m.leaf_a = take_leaf ? a : m.leaf_a;
-    m.leaf_b = take_leaf ? count : m.leaf_b;
+    if (SPEC) {
+        const bool leaf = ok && count != 0u;
+        const bool second = leaf && m.leaf_b != 0u, take_leaf = leaf && m.leaf_b == 0u;
+        m.node = second ? m.node : ((ok && count == 0u) ? a : esc);
+        *resume = take_leaf ? esc : *resume;
+        m.leaf_a = take_leaf ? a : m.leaf_a;
+        m.leaf_b = take_leaf ? count : m.leaf_b;
+        *stalled = second;
+    } else {
+        const bool take_leaf = ok && count != 0u;
+        m.node = (ok && count == 0u) ? a : esc;
+        m.leaf_a = take_leaf ? a : m.leaf_a;
+        m.leaf_b = take_leaf ? count : m.leaf_b;
+    }
 }
 // Moeller-Trumbore over the pending leaf, bvh.rs:91-138
 DI void mesh_leaf(const float4* __restrict__ t4, float t_min, MeshTrav& m) {

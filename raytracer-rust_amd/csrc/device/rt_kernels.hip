@@ -62,11 +62,14 @@ DI uint32_t fastdiv(uint32_t n, uint32_t mul, uint32_t shift) { return mul ? (__
 //    when one runs dry (work stealing), so one hot word never serialises all 6 k waves of the chip
 //    (measured: a single counter saturates near 88 atomics/us and made short runs 30 % slower).
 //  * Run length follows guided self-scheduling: (what was left in the shard at the wave's previous claim)
-//    / guided_div, clamped to [BATCH_MIN, BATCH_MAX] -- long runs while there is plenty of work (few atomics,
+//    / guided_div, clamped to [run_min, run_max] -- long runs while there is plenty of work (few atomics,
 //    coherent primary rays), short runs at the end so that all waves drain together.  This matters when one
 //    image is split across 8 GPUs and a launch lasts only a few ms.
 DI uint32_t xcc_id() { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & (WORK_SHARDS - 1u); }
-struct WorkCursor {
+// RMIN .. RMAX: the run lengths, compile-time (as kernel arguments they cost the Lambert-only kernel two more live scalar registers
+// in its hot loop and 5.7 % of its time).  RMIN == RMAX: fixed runs, no guided division.
+template <uint32_t RMIN, uint32_t RMAX>
+struct WorkCursorT {
     uint32_t next = 0, end = 0; bool no_more = false;
     uint32_t shard = 0, dry = 0, seen = 0;      // current shard, consecutive dry shards, last counter value seen in it
     DI void init() { shard = xcc_id(); }
@@ -79,7 +82,7 @@ struct WorkCursor {
             const uint32_t base = shard * P.shard_samples;
             const uint32_t len = min(P.shard_samples, P.band_samples > base ? P.band_samples - base : 0u);
             const uint32_t rem = len > seen ? len - seen : 0u;
-            const uint32_t size = min(max(rem / P.guided_div, BATCH_MIN), BATCH_MAX);
+            const uint32_t size = RMIN == RMAX ? RMAX : min(max(rem / P.guided_div, RMIN), RMAX);
             uint32_t start = 0;
             if (lane == 0) start = atomicAdd(P.batch_counter + shard * WORK_SHARD_STRIDE, size);
             start = __builtin_amdgcn_readfirstlane(start);
@@ -98,6 +101,8 @@ struct WorkCursor {
         return got;
     }
 };
+typedef WorkCursorT<BATCH_MIN, BATCH_MAX> WorkCursor;                    // lockstep kernels (and the reference build's mesh kernels)
+typedef WorkCursorT<RUN_WAVEFRONT_MIN, RUN_WAVEFRONT> WorkCursorWf;          // wavefront kernel: fixed, aligned runs (rt_device.h)
 
 // Decode a band-local sample index into (x, y, s) and key the path's RNG (renderer.rs:91-97).
 DI void start_path(const RenderParams& P, uint32_t sidx, RngCtr& rng, uint32_t& px, uint32_t& py) {
@@ -173,8 +178,8 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 // DEFAULTS: give the per-lane temporaries default values.  The lockstep kernels run without (every value is read only on the
 // path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %); the register allocation of the
 // state-machine / pool / wavefront kernels is better WITH them (wavefront: 38 spilled registers with, 120 without).
-template <bool SIMPLE, bool DEFAULTS = true>
-DI bool shade_and_regenerate(const RenderParams& P, WorkCursor& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
+template <bool SIMPLE, bool DEFAULTS = true, class WC>
+DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
     Rad* __restrict__ radiance = reinterpret_cast<Rad*>(P.radiance);

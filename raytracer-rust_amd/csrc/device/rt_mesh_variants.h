@@ -84,10 +84,10 @@ DI void render_ctr_state_machine(const RenderParams& P) {
                 if (wm == 0ull || __popcll(wm) * MI355RT_TRAV_BIAS < __popcll(lm)) break;
                 MI355RT_COUNT(0, wm);
                 if (walking) {
-                    mesh_step<FIXED_AABB, true>(n4, lds, lds_count, EPS, mt);
+                    mesh_step<FIXED_AABB, 1>(n4, lds, lds_count, EPS, mt);
 #pragma unroll
                     for (int u = 1; u < MI355RT_TRAV_UNROLL; ++u)
-                        if (mt.leaf_b == 0u && mt.node != NODE_END) mesh_step<FIXED_AABB, true>(n4, lds, lds_count, EPS, mt);
+                        if (mt.leaf_b == 0u && mt.node != NODE_END) mesh_step<FIXED_AABB, 1>(n4, lds, lds_count, EPS, mt);
                 }
             }
             MI355RT_COUNT(1, __ballot(state == ST_TRAV && mt.leaf_b != 0u));
@@ -120,7 +120,7 @@ DI void render_ctr_state_machine(const RenderParams& P) {
 #pragma unroll 1
                                 for (uint32_t k = 0; k < P.inline_steps; ++k) {
                                     if (mt.leaf_b != 0u || mt.node == NODE_END) break;
-                                    mesh_step<FIXED_AABB, true>(n4, lds, lds_count, EPS, mt);
+                                    mesh_step<FIXED_AABB, 1>(n4, lds, lds_count, EPS, mt);
                                 }
                                 if (mt.leaf_b == 0u && mt.node == NODE_END) walk_done = true;   // walked off the tree without meeting a leaf
                             }
@@ -280,7 +280,7 @@ DI void render_ctr_pool(const RenderParams& P) {
                 for (int u = 0; u < MI355RT_POOL_STEPS; ++u) {
 #pragma unroll
                     for (int w = 0; w < NW; ++w)
-                        if (has[w] && m[w].leaf_b == 0u && m[w].node != NODE_END) mesh_step<FIXED_AABB, true>(n4, lds, lds_count, EPS, m[w]);
+                        if (has[w] && m[w].leaf_b == 0u && m[w].node != NODE_END) mesh_step<FIXED_AABB, 1>(n4, lds, lds_count, EPS, m[w]);
                 }
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
@@ -362,7 +362,7 @@ DI void render_ctr_pool(const RenderParams& P) {
                                     // several meshes share the list: most rays miss a mesh's root box -- test it here and spare them the round trip
                                     // (the walker tests the root again for the others: same inputs, same result)
                                     const uint32_t root = mt.node;
-                                    mesh_step<FIXED_AABB, true>(n4, lds, lds_count, EPS, mt);
+                                    mesh_step<FIXED_AABB, 1>(n4, lds, lds_count, EPS, mt);
                                     gone = mt.leaf_b == 0u && mt.node == NODE_END;
                                     mt.node = root; mt.leaf_b = 0u; mt.leaf_a = 0u;
                                 }

@@ -29,13 +29,6 @@ namespace mi355rt {
 // than registers.  Measured when the kernel still had its TOP0 queue (semesterbild / teapot, 800x600x64, ms): 1 x 16 waves,
 // 1 728 slots 11.60 / 7.42;  2 x 12 waves, 832 slots each 10.65 / 6.65;  3 x 8 waves, 512 each 11.33 / 6.86;  2 x 14 at 72 VGPRs 14.8 / 9.8 and 2 x 16 at 64 VGPRs
 // 15.3 / 9.0 (spills);  2 x 10 at 96 VGPRs 15.2 / 9.7;  1 x 16 waves with 960 fat slots (36 dwords) 11.6 / 7.3.
-#ifndef MI355RT_WF_PATHS
-#define MI355RT_WF_PATHS 832                                // what fits beside seven rings (768 beside the eight there were: semesterbild +2.4 %, teapot +1.6 %)
-#endif
-#ifndef MI355RT_WF_RING
-#define MI355RT_WF_RING 1024
-#endif
-constexpr uint32_t WF_PATHS = MI355RT_WF_PATHS, WF_SLOT_WORDS = 20, WF_RING = MI355RT_WF_RING, WF_QUEUES = 7, WF_CTRL_WORDS = 32;
 constexpr uint32_t WF_EMPTY = 0xFFFFu, WF_WALK_DONE = 0x80000000u;
 // SHADE is four queues, one per material class of the hit: a pass whose slots all take the same branch of Material::scatter pays
 // for that branch only (a mixed pass pays for the sum of all branches that any of its lanes takes).
@@ -48,8 +41,7 @@ DI uint32_t shade_class(uint32_t kind) {
          : (kind == MI355RT_MAT_ROUGH_GGX || kind == MI355RT_MAT_ROUGH_BECKMANN) ? 2u
          : (kind == MI355RT_MAT_METAL || kind == MI355RT_MAT_DIELECTRIC) ? 3u : 1u;
 }
-constexpr uint32_t WF_LDS_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
-static_assert(WF_LDS_WORDS * 4u <= 163840u / 2u, "wavefront kernel LDS budget: two workgroups per CU");
+constexpr uint32_t WF_LDS_WORDS = WF_FIXED_WORDS + 8u * WF_LDS_NODES;
 static_assert(WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "a ring holds every slot number");
 // Slot layout, 5 x 16 bytes (the less a path carries, the more paths fit, and the fill of every pass follows from their number:
 // 960 slots of 36 dwords ran SHADE at 37 of 64 lanes):  q0 ro.xyz thr.x | q1 rd.xyz thr.y | q2 thr.z sidx ray_index cursor(+WALK_DONE) |
@@ -127,24 +119,42 @@ DI void render_ctr_wavefront(const RenderParams& P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_wf[WF_LDS_WORDS];
     WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + WF_CTRL_WORDS); Q.entry_spins = P.spin_limit_entry;
     uint32_t* const slots = s_wf + WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u;
+    // The top of the node array (stored top levels first, rt_api.cpp flatten_meshes) in what the slots leave of the LDS budget
+    const uint32_t lds_count = WF_LDS_NODES != 0u ? min(P.lds_nodes, WF_LDS_NODES) : 0u;
+    lds_nodes_t lds = (lds_nodes_t)(s_wf + WF_FIXED_WORDS);
     cprim_t prims = (cprim_t)(P.prims);
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = threadIdx.x; i < WF_QUEUES * WF_RING; i += blockDim.x) Q.rings[i] = (uint16_t)((i < WF_PATHS) ? i : WF_EMPTY);   // FREE holds every slot
     if (threadIdx.x < WF_CTRL_WORDS) Q.ctrl[threadIdx.x] = (threadIdx.x == 8u + WQ_FREE) ? WF_PATHS : 0u;
+    if (WF_LDS_NODES != 0u) { float4* s_nodes = reinterpret_cast<float4*>(s_wf + WF_FIXED_WORDS); for (uint32_t i = threadIdx.x; i < 2u * lds_count; i += blockDim.x) s_nodes[i] = n4[i]; }
     __syncthreads();
 
-    WorkCursor wc; wc.init();
+    WorkCursorWf wc; wc.init();
     uint32_t n_paths = 0, n_rays = 0, spins = 0, naps = 0;
     Prof prof; prof.begin();
     bool failed = false;
 #ifdef MI355RT_STAMPS
-    unsigned long long w_exec[4] = {0, 0, 0, 0}, w_lanes[4] = {0, 0, 0, 0};    // passes and slots per pass: 0 WALK, 1 TOP1, 2 (unused: there was a TOP0 stage), 3 SHADE (+ free fill)
+    unsigned long long w_exec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w_lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // passes and slots per pass: 0 WALK, 1 TOP1, 2 walks parked by a TOP pass, 3 SHADE (+ free fill),
+                                                                                                        // 4 box-test steps of WALK passes (lanes stepping), 5 leaf phases (lanes with a leaf), 6 WALK passes (walks finished), 7 inline steps in TOP
 #define MI355RT_WFCOUNT(i, n) do { w_exec[i] += 1; w_lanes[i] += (n); } while (0)
 #else
 #define MI355RT_WFCOUNT(i, n) do {} while (0)
 #endif
+#ifndef MI355RT_WF_LEAF_MIN
+#define MI355RT_WF_LEAF_MIN 0                               // lanes with a pending leaf below which a round's leaf phase is put off (0: never)
+#endif
+#ifndef MI355RT_WF_UNROLL
+#define MI355RT_WF_UNROLL 8                                 // copies of the box test in the WALK loop (the kernel is 49 KB of code; two CUs share a 64 KB instruction cache)
+#endif
+#ifndef MI355RT_WF_SPEC
+#define MI355RT_WF_SPEC 1                                   // WALK passes queue up to two hit leaves and keep stepping (see the WALK stage)
+#endif
+#ifndef MI355RT_WF_LDS_MODE
+#define MI355RT_WF_LDS_MODE 1                               // how a box test picks the LDS copy of the top nodes: 0 never, 1 whole wave below the cap, 2 per lane
+#endif
+    constexpr int WF_LDS_MODE = WF_LDS_NODES != 0u ? MI355RT_WF_LDS_MODE : 0;
 #ifndef MI355RT_WF_ROUNDS
 #define MI355RT_WF_ROUNDS 3                                 // rounds x steps (ms, semesterbild / teapot 64 spp): 1x8 11.8 / 7.5, 2x8 10.7 / 6.6, 3x8 10.4 / 6.4, 4x8 10.4 / 6.3, 8x8 10.7 / 6.6, 3x12 10.7 / 6.4
 #endif
@@ -171,7 +181,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                         if (!walk_done) {
                             MeshTrav mt; mesh_setup(pr, ro, rd, c.t, mt);
                             const uint32_t root = mt.node;
-                            mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);       // the root box, here: most rays miss it
+                            mesh_step<FIXED_AABB, WF_LDS_MODE>(n4, lds, lds_count, EPS, mt);       // the root box, here: most rays miss it
                             if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
                             else {
 #ifndef MI355RT_WF_INLINE_MIN
@@ -186,7 +196,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                                     for (int u = 0; u < MI355RT_WF_INLINE_STEPS; ++u) {
                                         if (mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
                                         if (mt.node == NODE_END) break;
-                                        mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, mt);
+                                        MI355RT_WFCOUNT(7, (uint32_t)__popcll(__ballot(true)));
+                                        mesh_step<FIXED_AABB, WF_LDS_MODE>(n4, lds, lds_count, EPS, mt);
                                     }
                                     if (mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
                                     if (mt.node == NODE_END) { mesh_accept(i, mt, rd, EPS, c); parked = true; }      // the whole walk fitted: the list goes on
@@ -212,6 +223,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         }
         uint32_t cls = 0u;
         if (have && !to_walk && c.idx != CAND_NONE) cls = shade_class(P.mats[P.prims[c.idx].material].kind);
+        MI355RT_WFCOUNT(2, (uint32_t)__popcll(__ballot(have && to_walk)));
         Q.push_each(have, to_walk ? (uint32_t)WQ_WALK : WQ_SHADE + cls, id, lane, failed);
     };
     for (;;) {
@@ -330,13 +342,54 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 mesh_setup(pr, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.f, m);                            // the object-space ray, as TOP computed it
                 m.node = __float_as_uint(w.x); m.best_t = w.y; m.best_tri = __float_as_uint(w.z);
             }
+#if MI355RT_WF_SPEC
+            // Speculative walk past a leaf.  In the reference's recursion a hit leaf is tested at once, because a triangle hit shrinks
+            // t_max for every box that follows (bvh.rs:148-156).  Most leaf tests MISS, and then the walk goes on exactly as if the leaf
+            // had not been there.  So a lane that reaches a leaf leaves it pending (leaf_a / leaf_b; `resume` = the node behind it) and
+            // keeps stepping with the unchanged best_t instead of idling until the wave's leaf phase (measured: box-test steps ran at
+            // 31 / 40 of 64 lanes on semesterbild / teapot); only a SECOND leaf stalls the lane, in front of that leaf's node.  The leaf
+            // phase tests the pending leaf; if it HITS, the speculation beyond it is void: the walk resumes at the node behind the leaf
+            // with the new best_t / best_tri.  Per ray this is the reference's sequence of accepted tests with the reference's t_max
+            // at each of them -- same results, bit for bit; the box tests beyond a hit and one repeated box test per stall are the
+            // only extra work.  (Two queued leaves per lane with a leaf phase per queue slot were measured too: the second slot's
+            // phases run nearly empty and cost more than the stalls they avoid -- +3 % / +7 %.)
+            uint32_t resume = NODE_END; bool stalled = false;
+            for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
+                if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
+#pragma unroll MI355RT_WF_UNROLL
+                for (int u = 0; u < MI355RT_WF_STEPS; ++u) {
+                    const bool stepping = have && !stalled && m.node != NODE_END;
+                    MI355RT_WFCOUNT(4, (uint32_t)__popcll(__ballot(stepping)));
+                    if (stepping) mesh_step<FIXED_AABB, WF_LDS_MODE, true>(n4, lds, lds_count, EPS, m, &resume, &stalled);
+                }
+#if MI355RT_WF_LEAF_MIN > 0
+                // a thin leaf phase is put off to the next round (the lanes keep stepping; those that reach a second leaf wait)
+                if (round + 1 < MI355RT_WF_ROUNDS && (uint32_t)__popcll(__ballot(have && m.leaf_b != 0u)) < (uint32_t)MI355RT_WF_LEAF_MIN &&
+                    __ballot(have && !stalled && m.node != NODE_END) != 0ull) continue;
+#endif
+                MI355RT_WFCOUNT(5, (uint32_t)__popcll(__ballot(have && m.leaf_b != 0u)));
+                if (have && m.leaf_b != 0u) {
+                    const uint32_t before = m.best_tri;
+                    mesh_leaf(t4, EPS, m);                                       // leaves m.leaf_b == 0
+                    if (m.best_tri != before) m.node = resume;                   // a hit: resume behind the leaf with the new best_t
+                }
+                stalled = false;
+            }
+#else
             for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
                 if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
 #pragma unroll
                 for (int u = 0; u < MI355RT_WF_STEPS; ++u)
-                    if (have && m.leaf_b == 0u && m.node != NODE_END) mesh_step<FIXED_AABB, false>(n4, nullptr, 0u, EPS, m);
+                    {
+                    const bool stepping = have && m.leaf_b == 0u && m.node != NODE_END;
+                    MI355RT_WFCOUNT(4, (uint32_t)__popcll(__ballot(stepping)));
+                    if (stepping) mesh_step<FIXED_AABB, WF_LDS_MODE>(n4, lds, lds_count, EPS, m);
+                }
+                MI355RT_WFCOUNT(5, (uint32_t)__popcll(__ballot(have && m.leaf_b != 0u)));
                 if (have && m.leaf_b != 0u) mesh_leaf(t4, EPS, m);
             }
+#endif
+            MI355RT_WFCOUNT(6, (uint32_t)__popcll(__ballot(have && m.leaf_b == 0u && m.node == NODE_END)));     // walks finished per WALK pass
             const bool done = have && m.leaf_b == 0u && m.node == NODE_END;        // (a pass always ends with its pending leaves tested: leaf_b == 0)
             if (have) {
                 reinterpret_cast<float4*>(sl)[4] = make_float4(__uint_as_float(m.node), m.best_t, __uint_as_float(m.best_tri), 0.f);
@@ -376,7 +429,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr);
 #ifdef MI355RT_STAMPS
         for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
-        for (int i = 0; i < 4; ++i) { atomicAdd(&P.stats[8 + 2 * i], w_exec[i]); atomicAdd(&P.stats[9 + 2 * i], w_lanes[i]); }
+        for (int i = 0; i < 8; ++i) { atomicAdd(&P.stats[8 + 2 * i], w_exec[i]); atomicAdd(&P.stats[9 + 2 * i], w_lanes[i]); }
 #endif
     }
     // A wave that gave up a bounded wait left paths unfinished: count it in the context's sticky error word, which the host reads

@@ -17,6 +17,8 @@ WL = {"cornell": ("data/scenes/tungsten/cornell-box/scene.json", 800, 600, 256, 
       "semesterbild": ("data/scenes/semesterbild.json", 800, 600, 64, 30, False),
       "veach": ("data/scenes/tungsten/veach-mis/scene.json", 1280, 720, 64, 16, False),
       "teapot": ("data/scenes/tungsten/teapot/scene.json", 800, 600, 64, 30, True)}
+if os.environ.get("AB_SPP"):          # samples per pixel for every workload (the mesh scenes default to 64)
+    WL = {k: (v[0], v[1], v[2], int(os.environ["AB_SPP"]), v[4], v[5]) for k, v in WL.items()}
 names = sys.argv[1:] or ["cornell"]
 import torch; torch.zeros(1, device="cuda")
 libs = {}

@@ -65,7 +65,12 @@ def main():
     ap.add_argument("--out", default="gpurun_out/pmc")
     ap.add_argument("--workloads", nargs="*", default=DEFAULT_WORKLOADS)
     ap.add_argument("--pass-timeout", type=int, default=300)
+    ap.add_argument("--groups", default="", help="JSON list of counter lists: an exploratory collection instead of the standard five passes "
+                                                 "(writes pmc_extra.json with the raw per-step sums only; never profiles/pmc_counters.json)")
     args = ap.parse_args()
+    extra = bool(args.groups)
+    if extra:
+        GROUPS[:] = json.loads(args.groups)
     build = importlib.import_module("raytracer-rust_amd.build")
     os.makedirs(args.out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
@@ -98,6 +103,11 @@ def main():
         s = summarize(wdir)
         r = s.get("k_render_ctr", {})
         rec = {"raw": s}
+        if extra:
+            doc["workloads"][wl] = rec
+            json.dump(doc, open(os.path.join(args.out, "pmc_extra.json"), "w"), indent=1, sort_keys=True)
+            print(wl, json.dumps({k: (round(v / 1e9, 4) if isinstance(v, float) else v) for k, v in sorted(r.items())}), "(x1e9 per step)", flush=True)
+            continue
         if not all(c in r for grp in GROUPS for c in grp):      # every pass ran, but a counter is missing from its CSV
             print(f"{wl}: counters missing from the CSVs {[c for grp in GROUPS for c in grp if c not in r]}: left out", flush=True)
             failed.append(wl)

@@ -18,17 +18,20 @@ for name, path, W, H, spp, depth, skip in [("cornell", "data/scenes/tungsten/cor
     ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings)
     out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
     st = ctx.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
-    raw = (C.c_ulonglong * 16)()
+    raw = (C.c_ulonglong * 32)()
     assert device.lib().mi355rt_debug_read_counters(ctx._h, raw) == 0
     acc = np.array(list(raw)[2:8], dtype=np.float64)
     print(f"{name}: kernel {st.render_kernel_ms:.2f} ms (stamped build), rays/sample {st.rays / st.samples:.2f}")
     for n, v in zip(NAMES, acc):
         if v: print(f"   {n:38s} {100 * v / acc.sum():6.2f} %")
-    blk = list(raw)[8:16]
+    blk = list(raw)[8:24]
     if sum(blk):
         rays = st.rays
         wf = ctx.kernel_variant() == 7
-        for i, n in enumerate(["WALK passes", "TOP1 passes", "(no TOP0 stage any more)", "SHADE+TOP0 passes"] if wf else ["inner-node steps", "leaf phases", "TOP passes", "SHADE passes"]):
+        names = (["WALK passes", "TOP1 passes", "TOP passes that park walks (lanes = walks parked)", "SHADE+TOP0 passes", "WALK box-test steps (lanes stepping)",
+                  "WALK leaf phases (lanes with a leaf)", "WALK passes (lanes = walks finished)", "inline box-test steps in TOP"] if wf
+                 else ["inner-node steps", "leaf phases", "TOP passes", "SHADE passes"])
+        for i, n in enumerate(names):
             e, l = blk[2 * i], blk[2 * i + 1]
-            if e: print(f"   {n:18s} executions per 64 rays {e / (rays / 64):7.2f}   mean lanes {l / e:5.1f}")
+            if e: print(f"   {n:52s} executions per 64 rays {e / (rays / 64):7.2f}   mean lanes {l / e:5.1f}")
     ctx.close()
