@@ -132,7 +132,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
     __syncthreads();
 
     WorkCursorWf wc; wc.init();
-    uint32_t n_paths = 0, n_rays = 0, spins = 0, naps = 0;
+    uint32_t n_paths = 0, n_rays = 0, spins = 0, naps = 0, seen_passes = 0;
     Prof prof; prof.begin();
     bool failed = false;
 #ifdef MI355RT_STAMPS
@@ -256,6 +256,14 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         if (stage == WQ_NONE) {
             if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
             __builtin_amdgcn_s_sleep(2);
+            // The watchdog measures lack of PROGRESS in the workgroup, not how long this wave has been idle: every pass ends with
+            // pushes, which move a queue tail, so an idle wave that sees the sum of the tails move starts counting again.  (A few
+            // waves tracing the last, very long paths of a band may keep the others idle for any length of time; that is not a
+            // failure.  A dedicated progress counter bumped per pass was measured first: +1.1 / +1.6 % -- one more hot LDS word.)
+            uint32_t passes = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < WF_QUEUES; ++q) passes += __hip_atomic_load(&Q.ctrl[8u + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (passes != seen_passes) { seen_passes = passes; spins = 0; }
             if (++spins > P.spin_limit_idle) { failed = true; }
             continue;
         }
