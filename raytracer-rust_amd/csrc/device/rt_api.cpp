@@ -398,21 +398,22 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     uint32_t n_mesh_prims = 0;
     for (const auto& pr : prims) n_mesh_prims += pr.kind == MI355RT_PRIM_MESH;
     const bool has_mesh = n_mesh_prims != 0;
-    bool simple_mats = true;                                         // only Lambertian (solid) / Emissive / Null?
-    for (uint32_t i = 0; i < sc->n_materials; ++i) {
-        const uint32_t k = sc->materials[i].kind;
-        simple_mats = simple_mats && (k == MI355RT_MAT_LAMBERT_SOLID || k == MI355RT_MAT_EMISSIVE || k == MI355RT_MAT_NULL);
-    }
+    uint32_t scene_mats = 0u;                                        // which material kinds a ray can meet (bit k = MI355RT_MAT_k): those the primitives refer to
+    for (uint32_t i = 0; i < sc->n_primitives; ++i) scene_mats |= MATBIT(sc->materials[sc->primitives[i].material].kind);
+    auto covers = [&](uint32_t variant) { return (scene_mats & ~mats_of_variant(variant)) == 0u; };
     ctx->has_mesh = has_mesh;
-    // Scenes with meshes: the wavefront kernel (path state in LDS, stage queues).  No mesh: a lockstep kernel, the
-    // Lambert-only instantiation when the materials allow it.  The library reads NO environment variables; the diagnostic hook
-    // mi355rt_debug_set_knob("kernel", v) may name another variant this library was built with (tests, tools/ab*.py).
-    ctx->variant = has_mesh ? KERNEL_WAVEFRONT : (simple_mats ? KERNEL_LOCKSTEP_SIMPLE : KERNEL_LOCKSTEP);
+    // Scenes with meshes: the wavefront kernel (path state in LDS, stage queues).  No mesh: a lockstep kernel.  In both
+    // families the most pruned instantiation whose material set covers the scene's (rt_device.h, mats_of_variant): the branches of
+    // the kinds a scene does not have are compiled out -- they set the register peak.  The library reads NO environment
+    // variables; the diagnostic hook mi355rt_debug_set_knob("kernel", v) may name another variant this library was built with.
+    if (has_mesh) ctx->variant = covers(KERNEL_WAVEFRONT_NOMETAL) ? KERNEL_WAVEFRONT_NOMETAL : KERNEL_WAVEFRONT;
+    else ctx->variant = covers(KERNEL_LOCKSTEP_SIMPLE) ? KERNEL_LOCKSTEP_SIMPLE : covers(KERNEL_LOCKSTEP_NOSPEC) ? KERNEL_LOCKSTEP_NOSPEC : KERNEL_LOCKSTEP;
     if (ctx->forced_variant >= 0) {
         const uint32_t v = (uint32_t)ctx->forced_variant;
-        const bool ok = render_ctr_variant_built(v) &&
-                        ((v == KERNEL_LOCKSTEP && !has_mesh) || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || (v == KERNEL_POOL && has_mesh) || v == KERNEL_WAVEFRONT ||
-                         (v == KERNEL_LOCKSTEP_SIMPLE && !has_mesh && simple_mats));
+        const bool mesh_free_only = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC;
+        const bool selectable = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || v == KERNEL_POOL || v == KERNEL_WAVEFRONT ||
+                                v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_NOMETAL;       // (the _FIXAABB forms follow options.flags)
+        const bool ok = render_ctr_variant_built(v) && selectable && covers(v) && !(mesh_free_only && has_mesh) && !(v == KERNEL_POOL && !has_mesh);
         if (ok) ctx->variant = v;
     }
     // Root-box test right at mesh set-up (reference build's kernels): the pool kernel always (rays that miss the root never leave
@@ -640,7 +641,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             const uint64_t np = std::min<uint64_t>(band_pixels_max, total_pixels - p0);
             p.band_pixel0 = (uint32_t)p0; p.band_samples = (uint32_t)(np * spp);
             p.batch_counter = ctx->counters.p + (size_t)b * ctr_words;
-            const bool wf = variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB;
+            const bool wf = is_wavefront(variant);
             const uint32_t run_min = wf ? RUN_WAVEFRONT_MIN : BATCH_MIN, run_max = wf ? RUN_WAVEFRONT : BATCH_MAX;   // what the kernel's WorkCursorT is compiled with
             p.shard_samples = (p.band_samples + WORK_SHARDS - 1) / WORK_SHARDS;
             p.shard_samples = (p.shard_samples + run_max - 1) / run_max * run_max;           // shards begin on run boundaries (fixed runs then stay aligned)
@@ -713,11 +714,11 @@ int mi355rt_debug_kernel_variant(mi355rt_context* ctx, uint32_t* out) {
     return MI355RT_OK;
 }
 
-// Diagnostic hook (not part of the public header): the STATS_WORDS (32) raw device counters of the last render.
-int mi355rt_debug_read_counters(mi355rt_context* ctx, unsigned long long* out32) {
-    if (!ctx || !out32 || !ctx->stats.p) return fail(MI355RT_ERR_INVALID, "no counters");
+// Diagnostic hook (not part of the public header): the STATS_WORDS (40) raw device counters of the last render.
+int mi355rt_debug_read_counters(mi355rt_context* ctx, unsigned long long* out40) {
+    if (!ctx || !out40 || !ctx->stats.p) return fail(MI355RT_ERR_INVALID, "no counters");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpy(out32, ctx->stats.p, STATS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out40, ctx->stats.p, STATS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MI355RT_OK;
 }
 

@@ -20,6 +20,7 @@
 //                             the path tracer and read once by the resolve kernel
 #pragma once
 #include <stdint.h>
+#include "../../../include/mi355rt.h"
 
 namespace mi355rt {
 
@@ -129,8 +130,23 @@ enum : uint32_t {
     KERNEL_POOL_FIXAABB = 6,
     KERNEL_WAVEFRONT = 7,        // path state in LDS, stages as queues: every pass runs with (nearly) full lanes (scenes with meshes)
     KERNEL_WAVEFRONT_FIXAABB = 8,
-    KERNEL_VARIANTS = 9
+    KERNEL_LOCKSTEP_NOSPEC = 9,  // KERNEL_LOCKSTEP without the metal and dielectric branches: 72 VGPRs = 7 waves per SIMD (veach-mis)
+    KERNEL_WAVEFRONT_NOMETAL = 10,   // KERNEL_WAVEFRONT without the metal branch (teapot, semesterbild)
+    KERNEL_VARIANTS = 11
 };
+// Material sets (bit k = kind MI355RT_MAT_k may occur) the kernels are instantiated for; set_scene picks, per kernel family, the
+// most pruned instantiation whose set covers the scene's materials.  The branches compiled out set the register peak.
+constexpr uint32_t MATBIT(uint32_t kind) { return 1u << kind; }
+constexpr uint32_t MATS_ALL = (1u << MI355RT_MAT_KIND_COUNT) - 1u;
+constexpr uint32_t MATS_TERMINAL = MATBIT(MI355RT_MAT_EMISSIVE) | MATBIT(MI355RT_MAT_NULL);                       // never scatter: in every set
+constexpr uint32_t MATS_LAMBERT = MATS_TERMINAL | MATBIT(MI355RT_MAT_LAMBERT_SOLID);
+constexpr uint32_t MATS_DIFFUSE = MATS_LAMBERT | MATBIT(MI355RT_MAT_LAMBERT_CHECKER) | MATBIT(MI355RT_MAT_TEXTURE) | MATBIT(MI355RT_MAT_PLASTIC);
+constexpr uint32_t MATS_ROUGH = MATBIT(MI355RT_MAT_ROUGH_GGX) | MATBIT(MI355RT_MAT_ROUGH_BECKMANN);
+constexpr uint32_t MATS_NO_METAL = MATS_ALL & ~MATBIT(MI355RT_MAT_METAL);
+constexpr uint32_t MATS_NO_SPECULAR = MATS_ALL & ~(MATBIT(MI355RT_MAT_METAL) | MATBIT(MI355RT_MAT_DIELECTRIC));
+inline uint32_t mats_of_variant(uint32_t variant) {
+    return variant == KERNEL_LOCKSTEP_SIMPLE ? MATS_LAMBERT : variant == KERNEL_LOCKSTEP_NOSPEC ? MATS_NO_SPECULAR : variant == KERNEL_WAVEFRONT_NOMETAL ? MATS_NO_METAL : MATS_ALL;
+}
 
 struct ResolveParams {
     const float* radiance;       // 3 floats per band sample
@@ -202,7 +218,11 @@ static_assert(WF_FIXED_WORDS <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budge
 #endif
 constexpr uint32_t WF_LDS_NODES = MI355RT_WF_LDS_NODES >= 0 ? (uint32_t)MI355RT_WF_LDS_NODES : (WF_LDS_BUDGET_WORDS - WF_FIXED_WORDS) / 8u;    // 32-byte nodes
 static_assert(WF_FIXED_WORDS + 8u * WF_LDS_NODES <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budget (node copy)");
-constexpr uint32_t STATS_WORDS = 32;                         // u64 device counters per render: [0] paths, [1] rays, the rest diagnostic builds only
-inline uint32_t block_threads_of(uint32_t variant) { return variant >= 7u ? BLOCK_THREADS_WF : (variant == 2u || variant >= 4u) ? BLOCK_THREADS_SM : BLOCK_THREADS; }   // KERNEL_WAVEFRONT*, KERNEL_STATE_MACHINE* / KERNEL_POOL*
+constexpr uint32_t STATS_WORDS = 40;                         // u64 device counters per render: [0] paths, [1] rays, the rest diagnostic builds only
+inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB || variant == KERNEL_WAVEFRONT_NOMETAL; }
+inline uint32_t block_threads_of(uint32_t variant) {
+    return is_wavefront(variant) ? BLOCK_THREADS_WF
+         : (variant == KERNEL_STATE_MACHINE || variant == KERNEL_STATE_MACHINE_FIXAABB || variant == KERNEL_POOL || variant == KERNEL_POOL_FIXAABB) ? BLOCK_THREADS_SM : BLOCK_THREADS;
+}
 
 }  // namespace mi355rt

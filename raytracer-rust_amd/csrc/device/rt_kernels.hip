@@ -178,7 +178,7 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 // DEFAULTS: give the per-lane temporaries default values.  The lockstep kernels run without (every value is read only on the
 // path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %); the register allocation of the
 // state-machine / pool / wavefront kernels is better WITH them (wavefront: 38 spilled registers with, 120 without).
-template <bool SIMPLE, bool DEFAULTS = true, class WC>
+template <uint32_t MATS, bool DEFAULTS = true, class WC>
 DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
@@ -200,8 +200,8 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
     bool fresh = false;
     if (wc.deal(P, can_take && !live, lane, ps.sidx)) { start_path(P, ps.sidx, ps.rng, ps.px, ps.py); fresh = true; live = true; ++n_paths; }
     if (__ballot(live) == 0ull) return !wc.exhausted();
-    bool diffuse = false, scattered = false;
-    f3 raw, atten, emitted; float side;              // written by the branch a lane takes below, read only on that lane's own path
+    uint32_t ball_use = BALL_NONE; bool scattered = false;
+    f3 raw, atten, emitted; float side, fuzz = 0.f;  // written by the branch a lane takes below, read only on that lane's own path
     if constexpr (DEFAULTS) {
         raw = mk(0.f, 0.f, 1.f); atten = mk(0.f, 0.f, 0.f); emitted = mk(0.f, 0.f, 0.f); side = EPS;
         if (live) {
@@ -215,14 +215,14 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
                 ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
                 if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
             } else {
-                scattered = scatter_pre<SIMPLE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, diffuse);
+                scattered = scatter_pre<MATS>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
             }
         }
         prof.mark(5);
-        const f3 ball = unit_ball_cooperative(diffuse, ps.rng, lane);                        // whole wave, uniform control flow
+        const f3 ball = unit_ball_cooperative(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
         if (live && !fresh) {
+            if (scattered) scattered = ball_finish(ball_use, h, ball, fuzz, raw);            // (a fuzzed metal reflection may still be absorbed)
             if (scattered) {
-                if (diffuse) raw = diffuse_finish(h, ball);
                 ps.thr = ps.thr * atten; ps.ro = scatter_origin(h, side); ++ps.ray_index;
                 if (ps.ray_index == P.max_depth) {                                           // next level has depth == 0 (renderer.rs:20-22)
                     const f3 L = ps.thr * mk(0.f, 0.f, 0.f);
@@ -251,14 +251,15 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
                 n_thr = mk(1.f, 1.f, 1.f); n_ri = 0;
                 if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
             } else {
-                scattered = scatter_pre<SIMPLE, true>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, diffuse);
+                scattered = scatter_pre<MATS, true>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
             }
         }
         prof.mark(5);
-        const f3 ball = unit_ball_cooperative<true>(diffuse, ps.rng, lane);                        // whole wave, uniform control flow
+        prof.classes(live && !fresh, live && fresh, __float_as_uint(q0.x));
+        const f3 ball = unit_ball_cooperative<true>(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
         if (live && !fresh) {
+            if (scattered) scattered = ball_finish(ball_use, h, ball, fuzz, raw);            // (a fuzzed metal reflection may still be absorbed)
             if (scattered) {
-                if (diffuse) raw = diffuse_finish(h, ball);
                 n_thr = ps.thr * atten; n_ro = scatter_origin(h, side); n_ri = ps.ray_index + 1u;
                 if (n_ri == P.max_depth) {                                                   // next level has depth == 0 (renderer.rs:20-22)
                     const f3 L = n_thr * mk(0.f, 0.f, 0.f);
@@ -314,8 +315,9 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
 #ifndef MI355RT_GENERAL_CARRY_PO
 #define MI355RT_GENERAL_CARRY_PO true                       // the general mesh-free kernel carries the cube hit point too (see hit_scene): pays at 80 VGPRs
 #endif
-template <bool HAS_MESH, bool SIMPLE>
+template <bool HAS_MESH, uint32_t MATS>
 DI void render_ctr_lockstep(const RenderParams& P) {
+    constexpr bool SIMPLE = (MATS & ~MATS_LAMBERT) == 0u;
     cprim_t prims = (cprim_t)(P.prims);
     const uint32_t lane = threadIdx.x & 63u;
     WorkCursor wc; wc.init();
@@ -332,7 +334,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         Hit h; bool hit = false;                           // h is read only where `hit` says it was written: no default values to copy around
         if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<SIMPLE, false>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths
@@ -342,7 +344,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
 #endif
     }
 #ifdef MI355RT_STAMPS
-    if (lane == 0 && P.stats) for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]);
+    if (lane == 0 && P.stats) { for (int i = 0; i < 6; ++i) atomicAdd(&P.stats[2 + i], prof.acc[i]); for (int i = 0; i < 10; ++i) atomicAdd(&P.stats[24 + i], prof.cls[i]); }
     if (P.wave_times) {
         const unsigned long long t_wave1 = __builtin_amdgcn_s_memrealtime();
         const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -357,20 +359,25 @@ DI void render_ctr_lockstep(const RenderParams& P) {
     if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }
 }
 
+#ifndef MI355RT_AB_LS_MATS
+#define MI355RT_AB_LS_MATS MATS_ALL
+#endif
 // Entry points: one body, instantiated per scene class so that each gets its own register budget.
 //   k_render_ctr_nomesh  any materials, no mesh in the list            (veach-mis)                7 waves/SIMD
 //   k_render_ctr_simple  Lambertian/Emissive/Null only, no mesh        (cornell: -3 % vs nomesh)   7 waves/SIMD
+//   k_render_ctr_nospec  no metal, no dielectric, no mesh              (veach-mis: -2.5 % vs nomesh) 7 waves/SIMD
 //   k_render_ctr_mesh    lockstep with the per-lane BVH walk inlined   (A/B reference for the state machine)
-__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_nomesh(const RenderParams P) { render_ctr_lockstep<false, false>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_simple(const RenderParams P) { render_ctr_lockstep<false, true>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_render_ctr_mesh(const RenderParams P) { render_ctr_lockstep<true, false>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_nomesh(const RenderParams P) { render_ctr_lockstep<false, MI355RT_AB_LS_MATS>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_simple(const RenderParams P) { render_ctr_lockstep<false, MATS_LAMBERT>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_nospec(const RenderParams P) { render_ctr_lockstep<false, MATS_NO_SPECULAR>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_render_ctr_mesh(const RenderParams P) { render_ctr_lockstep<true, MATS_ALL>(P); }
 
 }  // namespace mi355rt
 
 // The two earlier generations of the mesh path -- the in-wave state machine and the LDS walk pool -- are retired from the product
 // library: they are compiled only into the tests' reference build (-DMI355RT_REFS, build.build_device_variant("refs")), where they
-// serve as bit-identity references for the wavefront kernel.  k_render_ctr_mesh above stays: it is the product's fallback for
-// scenes beyond the wavefront kernel's packed-slot limits (rt_wavefront.h) and the simplest reference of the BVH walk.
+// serve as bit-identity references for the wavefront kernel.  k_render_ctr_mesh above stays in the product library: the plain
+// per-lane loop is the simplest statement of the BVH walk and what the diagnostic knob "kernel" = 1 selects.
 #ifdef MI355RT_REFS
 #include "rt_mesh_variants.h"   // k_render_ctr_sm, k_render_ctr_pool (use the shared pieces above)
 #endif
@@ -522,6 +529,8 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
         case KERNEL_LOCKSTEP:        hipLaunchKernelGGL(k_render_ctr_nomesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_MESH:   hipLaunchKernelGGL(k_render_ctr_mesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_SIMPLE: hipLaunchKernelGGL(k_render_ctr_simple, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_LOCKSTEP_NOSPEC: hipLaunchKernelGGL(k_render_ctr_nospec, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_WAVEFRONT_NOMETAL: hipLaunchKernelGGL(k_render_ctr_wf_nometal, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT:       hipLaunchKernelGGL(k_render_ctr_wf, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_FIXAABB: hipLaunchKernelGGL(k_render_ctr_wf_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
 #ifdef MI355RT_REFS
@@ -538,7 +547,8 @@ bool render_ctr_variant_built(uint32_t variant) {
 #ifdef MI355RT_REFS
     return variant < KERNEL_VARIANTS;
 #else
-    return variant == KERNEL_LOCKSTEP || variant == KERNEL_LOCKSTEP_MESH || variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB;
+    return variant == KERNEL_LOCKSTEP || variant == KERNEL_LOCKSTEP_MESH || variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_LOCKSTEP_NOSPEC ||
+           is_wavefront(variant);
 #endif
 }
 int launch_resolve(const ResolveParams& p, void* stream) {
@@ -555,6 +565,8 @@ int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs,
     const void* fn = variant == KERNEL_LOCKSTEP ? reinterpret_cast<const void*>(k_render_ctr_nomesh)
                    : variant == KERNEL_LOCKSTEP_MESH ? reinterpret_cast<const void*>(k_render_ctr_mesh)
                    : variant == KERNEL_LOCKSTEP_SIMPLE ? reinterpret_cast<const void*>(k_render_ctr_simple)
+                   : variant == KERNEL_LOCKSTEP_NOSPEC ? reinterpret_cast<const void*>(k_render_ctr_nospec)
+                   : variant == KERNEL_WAVEFRONT_NOMETAL ? reinterpret_cast<const void*>(k_render_ctr_wf_nometal)
                    : variant == KERNEL_WAVEFRONT ? reinterpret_cast<const void*>(k_render_ctr_wf)
 #ifdef MI355RT_REFS
                    : variant == KERNEL_STATE_MACHINE_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_sm_fixaabb)

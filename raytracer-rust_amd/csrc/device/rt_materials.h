@@ -55,8 +55,11 @@ DI float beckmann_lambda(float a, float x) {                                    
 // Split in two so that the counter-mode kernels can run the unit-ball rejection of the Lambert-style bounce
 // wave-cooperatively between the halves: scatter_pre() decides everything except that direction (it sets
 // `diffuse`), diffuse_finish() turns the accepted unit-ball point into the scattered ray (material.rs:54-62).
-// SIMPLE: the scene's materials are only Lambertian (solid) / Emissive / Null (checked on the host), so every
-// scattering material is the Lambert bounce and the other BSDFs -- which set the register peak -- are compiled out.
+// MATS: bit k set = a material of kind k (MI355RT_MAT_*) may occur.  mi355rt_context_set_scene knows which kinds the scene holds
+// and picks a kernel instantiated for a superset; the branches of the other kinds are compiled out.  They set the register
+// peak: the metal's fuzz loop and the rough conductor together cost the wavefront kernel 49 of its 50 spilled registers
+// (measured per branch), and the Lambert-only lockstep kernel (cornell) runs 7 waves per SIMD because of it.
+// MATS_LAMBERT: only Lambertian (solid) / Emissive / Null -- every scattering material is the Lambert bounce, no dispatch at all.
 // tungsten/parser.rs:222-240: TextureMaterial's texel, looked up by the hit NORMAL (equirectangular, nearest), as a colour in [0, 1]
 DI f3 texture_lookup(const DevTexture* __restrict__ texs, uint32_t index, float h_offset, f3 n) {
     const DevTexture t = texs[index];
@@ -71,34 +74,37 @@ DI f3 texture_lookup(const DevTexture* __restrict__ texs, uint32_t index, float 
     return mk((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);   // :237-241
 }
 
-template <bool SIMPLE, bool WIDE = false, class Rng>
-DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, float& side, f3& raw_d, f3& atten, f3& emitted, bool& diffuse_out) {
+enum : uint32_t { BALL_NONE = 0, BALL_DIFFUSE = 1, BALL_METAL = 2 };    // what a scatter event needs a random_in_unit_sphere point for
+template <uint32_t MATS, bool WIDE = false, class Rng>
+DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, float& side, f3& raw_d, f3& atten, f3& emitted, uint32_t& ball_use, float& fuzz_out) {
     const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
     const uint32_t kind = __float_as_uint(q0.x);
     const f3 albedo = mk(q0.y, q0.z, q0.w);
     const bool front_face = (h.mat_ff >> 31) != 0;
     emitted = mk(0.f, 0.f, 0.f);
-    diffuse_out = false;
+    ball_use = BALL_NONE;
     side = EPS;                                                                    // every material but the dielectric leaves on the normal's side
     if (kind == MI355RT_MAT_EMISSIVE) { emitted = albedo; return false; }         // material.rs:179-191
     if (kind == MI355RT_MAT_NULL) return false;                                   // material.rs:239-251
     rng.begin_scatter();
     bool diffuse = false;                                                          // Lambert-style bounce shared by 3 materials
     atten = albedo;
+    constexpr bool SIMPLE = (MATS & ~MATS_LAMBERT) == 0u;
+#define MI_HAS(k) (((MATS >> (k)) & 1u) != 0u)
     if (SIMPLE || kind == MI355RT_MAT_LAMBERT_SOLID) {                             // material.rs:47-71
         diffuse = true;
-    } else if (kind == MI355RT_MAT_LAMBERT_CHECKER) {                              // tungsten/materials.rs:89-99
+    } else if (MI_HAS(MI355RT_MAT_LAMBERT_CHECKER) && kind == MI355RT_MAT_LAMBERT_CHECKER) {                              // tungsten/materials.rs:89-99
         const float4 q1 = m4[1];
         float inv_scale = q1.w;
         int32_t sum = (int32_t)((uint32_t)as_i32_sat(floorf(h.p.x * inv_scale)) + (uint32_t)as_i32_sat(floorf(h.p.y * inv_scale)) +
                                 (uint32_t)as_i32_sat(floorf(h.p.z * inv_scale)));
         if ((sum & 1) != 0) atten = mk(q1.x, q1.y, q1.z);
         diffuse = true;
-    } else if (kind == MI355RT_MAT_TEXTURE) {                                      // tungsten/parser.rs:205-243
+    } else if (MI_HAS(MI355RT_MAT_TEXTURE) && kind == MI355RT_MAT_TEXTURE) {                                      // tungsten/parser.rs:205-243
         const float4 q1 = m4[1];
         atten = albedo * texture_lookup(texs, __float_as_uint(m4[3].w), q1.w, h.n);
         diffuse = true;
-    } else if (kind == MI355RT_MAT_PLASTIC) {                                      // tungsten/materials.rs:29-65
+    } else if (MI_HAS(MI355RT_MAT_PLASTIC) && kind == MI355RT_MAT_PLASTIC) {                                      // tungsten/materials.rs:29-65
         float ior = m4[1].w;
         float dn = dot(rd_in, h.n);
         float cosine = (dn > 0.0f) ? ior * dn / len(rd_in) : -dn / len(rd_in);
@@ -109,18 +115,15 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
         } else {
             diffuse = true;
         }
-    } else if (kind == MI355RT_MAT_METAL) {                                        // material.rs:87-110
-        float fuzz = m4[1].w;
-        f3 reflected = mat_reflect(normalized(rd_in), h.n);
-        f3 fuzzed = reflected;
-        if (fuzz > 0.0f) {
-            f3 p; uint32_t j = 0;
-            do { p = rng.template cube_point<WIDE>(j); ++j; } while (!(len2(p) < 1.0f));   // vec3.rs:54-61
-            fuzzed = reflected + p * fuzz;
-        }
-        if (!(dot(fuzzed, h.n) > 0.0f)) return false;
-        raw_d = fuzzed;
-    } else if (kind == MI355RT_MAT_DIELECTRIC) {                                   // material.rs:122-162
+    } else if (MI_HAS(MI355RT_MAT_METAL) && kind == MI355RT_MAT_METAL) {                                        // material.rs:87-110
+        // The fuzz's random_in_unit_sphere (material.rs:97) is the same rejection loop as the Lambert bounce's, with the same
+        // addressed draws (try j = block j words 1..3): it is left to the caller's wave-cooperative rejection and ball_finish()
+        // adds it.  (As a per-lane loop with a Philox call in it, this branch set the register peak of every general kernel.)
+        const float fuzz = m4[1].w;
+        raw_d = mat_reflect(normalized(rd_in), h.n);
+        if (fuzz > 0.0f) { ball_use = BALL_METAL; fuzz_out = fuzz; diffuse = false; }
+        else if (!(dot(raw_d, h.n) > 0.0f)) return false;
+    } else if (MI_HAS(MI355RT_MAT_DIELECTRIC) && kind == MI355RT_MAT_DIELECTRIC) {                                   // material.rs:122-162
         float ri = m4[1].w;
         float ratio = front_face ? (1.0f / ri) : (ri / 1.0f);
         f3 unit = normalized(rd_in);
@@ -140,7 +143,7 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
         side = (dot(dir, h.n) > 0.0f) ? EPS : -EPS;                                // p - n*EPS == p + n*(-EPS) bit for bit
         raw_d = dir;
         atten = mk(1.f, 1.f, 1.f);
-    } else {                                                                       // RoughConductor, tungsten/materials.rs:306-377
+    } else if ((MATS & MATS_ROUGH) != 0u) {                                        // RoughConductor, tungsten/materials.rs:306-377 (the two kinds that are left)
         const bool ggx = (kind == MI355RT_MAT_ROUGH_GGX);
         if (has_nan(rd_in)) return false;
         if (has_nan(h.n) || is_zero(h.n)) return false;
@@ -188,12 +191,20 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
         atten = (den > EPS) ? albedo * divf(num, den) : mk(0.f, 0.f, 0.f);
         raw_d = l;
     }
-    diffuse_out = diffuse;
+#undef MI_HAS
+    if (diffuse) ball_use = BALL_DIFFUSE;
     return true;
 }
 DI f3 diffuse_finish(const Hit& h, f3 p) {                                          // material.rs:54-62
     f3 dir = h.n + normalized(p);
     return near_zero(dir) ? h.n : dir;
+}
+// What the accepted unit-ball point turns into: the Lambert-style direction, or the metal's fuzzed reflection, which may be absorbed
+// (material.rs:97-104: `reflected + fuzz * p`, None unless it leaves on the normal's side).  Returns false when absorbed.
+DI bool ball_finish(uint32_t ball_use, const Hit& h, f3 p, float fuzz, f3& raw) {
+    if (ball_use == BALL_DIFFUSE) raw = diffuse_finish(h, p);
+    else if (ball_use == BALL_METAL) { raw = raw + p * fuzz; return dot(raw, h.n) > 0.0f; }
+    return true;
 }
 // What every scatter() and Camera::get_ray end with: `.normalized()` of the direction, then Ray::new normalises again
 // (ray.rs:12-17) -- and the origin offset along the normal.  The callers run it ONCE for all lanes of the wave, whatever
@@ -203,12 +214,12 @@ DI f3 scatter_origin(const Hit& h, float side) { return h.p + h.n * side; }
 // Sequential composition (reference-stream replay kernel): random_in_unit_sphere as the plain loop, vec3.rs:54-61.
 template <class Rng>
 DI bool surface_scatter(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, f3& new_o, f3& new_d, f3& atten, f3& emitted) {
-    bool diffuse = false; float side = EPS; f3 raw = mk(0.f, 0.f, 1.f);
-    if (!scatter_pre<false>(mats, texs, q0, h, rd_in, rng, side, raw, atten, emitted, diffuse)) return false;
-    if (diffuse) {
+    uint32_t ball_use = BALL_NONE; float side = EPS, fuzz = 0.f; f3 raw = mk(0.f, 0.f, 1.f);
+    if (!scatter_pre<MATS_ALL>(mats, texs, q0, h, rd_in, rng, side, raw, atten, emitted, ball_use, fuzz)) return false;
+    if (ball_use != BALL_NONE) {
         f3 p; uint32_t j = 0;
         do { p = rng.cube_point(j); ++j; } while (!(len2(p) < 1.0f));
-        raw = diffuse_finish(h, p);
+        if (!ball_finish(ball_use, h, p, fuzz, raw)) return false;
     }
     new_o = scatter_origin(h, side); new_d = ray_direction(raw);
     return true;

@@ -19,7 +19,14 @@ typedef const __attribute__((address_space(4))) DevPrim* cprim_t;   // wave-unif
 #ifdef MI355RT_STAMPS
 struct Prof {
     unsigned long long acc[6]; unsigned long long last;
-    DI void begin() { for (int i = 0; i < 6; ++i) acc[i] = 0; last = now(); }
+    unsigned long long cls[10];     // lockstep kernels: per branch of the shading step {iterations in which any lane takes it, lanes that take it}:
+                                   // 0 rough conductor, 1 Lambert-style bounce (Lambert, checker, texture, plastic), 2 metal / dielectric, 3 camera ray, 4 every iteration / live lanes
+    DI void begin() { for (int i = 0; i < 6; ++i) acc[i] = 0; for (int i = 0; i < 10; ++i) cls[i] = 0; last = now(); }
+    DI void classes(bool cont, bool fresh, uint32_t kind) {
+        const unsigned long long m[5] = {__ballot(cont && (kind == 6u || kind == 7u)), __ballot(cont && (kind == 0u || kind == 1u || kind == 5u || kind == 9u)),
+                                         __ballot(cont && (kind == 2u || kind == 3u)), __ballot(fresh), __ballot(cont || fresh)};
+        for (int i = 0; i < 5; ++i) { cls[2 * i] += m[i] != 0ull; cls[2 * i + 1] += (unsigned long long)__popcll(m[i]); }
+    }
     DI static unsigned long long now() {
         unsigned long long t; __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
@@ -28,7 +35,7 @@ struct Prof {
     DI void mark(int i) { unsigned long long t = now(); acc[i] += t - last; last = t; }
 };
 #else
-struct Prof { DI void begin() {} DI void mark(int) {} };
+struct Prof { DI void begin() {} DI void mark(int) {} DI void classes(bool, bool, uint32_t) {} };
 #endif
 
 

@@ -142,7 +142,7 @@ DI void render_ctr_state_machine(const RenderParams& P) {
         if (any_hit) finish_hit<true>(P.prims, P.tris, best, ps.ro, ps.rd, h);             // the winner's HitRecord, once per ray
         const bool part = live || state == ST_IDLE;
         MI355RT_COUNT(3, __ballot(part));
-        shade_and_regenerate<false>(P, wc, lane, live, part, any_hit, h, ps, n_paths, n_rays, prof);
+        shade_and_regenerate<MATS_ALL>(P, wc, lane, live, part, any_hit, h, ps, n_paths, n_rays, prof);
         if (part) {
             if (live) { state = ST_TOP; cursor = 0; cand_reset(best); walk_done = false; }
             else state = ST_IDLE;
@@ -402,7 +402,7 @@ DI void render_ctr_pool(const RenderParams& P) {
         Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
         if (any_hit) finish_hit<true>(P.prims, P.tris, best, ps.ro, ps.rd, h);
         const bool part = live || state == ST_IDLE;
-        shade_and_regenerate<false>(P, wc, lane, live, part, any_hit, h, ps, n_paths, n_rays, prof);
+        shade_and_regenerate<MATS_ALL>(P, wc, lane, live, part, any_hit, h, ps, n_paths, n_rays, prof);
         if (part) {
             if (live) { state = ST_TOP; cursor = 0; cand_reset(best); walk_done = false; }
             else state = ST_IDLE;

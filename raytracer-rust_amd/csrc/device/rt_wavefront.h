@@ -114,7 +114,7 @@ struct WfQueues {
     }
 };
 
-template <bool FIXED_AABB>
+template <bool FIXED_AABB, uint32_t MATS>
 DI void render_ctr_wavefront(const RenderParams& P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_wf[WF_LDS_WORDS];
     WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + WF_CTRL_WORDS); Q.entry_spins = P.spin_limit_entry;
@@ -313,7 +313,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             const bool any_hit = have && c.idx != CAND_NONE;
             Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
             if (any_hit) finish_hit<true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
-            shade_and_regenerate<false>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
+            shade_and_regenerate<MATS>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
             if (live) {                                                          // a ray to trace: continuing or freshly generated
                 reinterpret_cast<float4*>(sl)[0] = make_float4(ps.ro.x, ps.ro.y, ps.ro.z, ps.thr.x);
                 reinterpret_cast<float4*>(sl)[1] = make_float4(ps.rd.x, ps.rd.y, ps.rd.z, ps.thr.y);
@@ -448,8 +448,13 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #define MI355RT_OCC_WF 6
 #endif
 #define MI355RT_OCC_WFK __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_WF, MI355RT_OCC_WF)))
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true>(P); }
+#ifndef MI355RT_AB_WF_MATS
+#define MI355RT_AB_WF_MATS MATS_ALL
+#endif
+// Entry points: one body per material set (rt_device.h); the opt-in slab test only in the general form.
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MATS>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true, MATS_ALL>(P); }
 
 
 }  // namespace mi355rt

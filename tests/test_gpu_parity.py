@@ -126,8 +126,12 @@ def test_mesh_kernels_equal_the_lockstep_walk(name, native, oracle_mod, abi, kno
     assert not device.lib().mi355rt_debug_has_variant(2) and not device.lib().mi355rt_debug_has_variant(5)     # retired from the product library
     assert R.mi355rt_debug_has_variant(2) and R.mi355rt_debug_has_variant(5)
     sc = load_for_both(name, oracle_mod, host, width=96, height=64, spp=6, max_depth=12)
+    ctx = device.Context(0)
+    ctx.set_scene(sc, sc.camera, sc.settings)
+    assert ctx.kernel_variant() == 10                      # neither scene has a metal: the wavefront kernel without that branch is the automatic choice
+    ctx.close()
     outs = []
-    for library, kv in ((None, {"kernel": 1}), (None, {}), (None, {"kernel": 7}),
+    for library, kv in ((None, {"kernel": 1}), (None, {}), (None, {"kernel": 7}), (None, {"kernel": 10}),
                         (R, {"kernel": 1}), (R, {"kernel": 7}),
                         (R, {"kernel": 2, "trav_min": 1}), (R, {"kernel": 2, "trav_min": 64}), (R, {"kernel": 2}),
                         (R, {"kernel": 5}), (R, {"kernel": 5, "walkers": 9, "trav_min": 1}),                  # walk pool: 4 and 9 walker waves
@@ -170,13 +174,26 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, knobs):
     op, ol, cnt = oracle_mod.render(sc, sc.camera, sc.settings, abi.Options.make())
     assert np.array_equal(gl.view(np.uint32), ol.reshape(-1).view(np.uint32)) and cnt.rays == rays
 
+    # veach-mis has Lambert + Emissive + Beckmann conductors: no metal, no dielectric -> the general kernel's instantiation without those
+    # two branches (9, 7 waves per SIMD).  It must equal the general kernel (0) bit for bit, and the Lambert-only one must be refused.
     sv = load_for_both("veach", oracle_mod, host, width=80, height=48, spp=4, max_depth=8)
     knobs()
-    vv, _, vl, _ = run(sv)
+    vv, vp, vl, vr = run(sv)
     knobs(kernel=3)                                       # refused: the scene has RoughConductor materials
     vv3, _, vl3, _ = run(sv)
-    assert (vv, vv3) == (0, 0)
+    knobs(kernel=0)
+    vv0, vp0, vl0, vr0 = run(sv)
+    assert (vv, vv3, vv0) == (9, 9, 0)
     assert np.array_equal(vl.view(np.uint32), vl3.view(np.uint32))
+    assert np.array_equal(vl.view(np.uint32), vl0.view(np.uint32)) and np.array_equal(vp, vp0) and vr == vr0
+    # a scene with a metal in it is refused by the pruned instantiation
+    from fuzz_scenes import random_scene
+    sm = random_scene(abi, host, 31, exact_only=True, n_prims=16, only_kinds=[2, 2, 3, 0, 1, 3, 3, 0, 0, 2, 1, 1])
+    sm.settings = abi.Settings(40, 30, 3, 6)
+    kinds = {sm.c.materials[sm.c.primitives[i].material].kind for i in range(sm.c.n_primitives)}
+    assert abi.MAT_METAL in kinds or abi.MAT_DIELECTRIC in kinds
+    knobs(kernel=9)
+    assert run(sm)[0] == 0
 
 
 def test_fixed_wo3_reader_scene_is_bit_identical_to_the_oracle(native, oracle_mod, abi):

@@ -18,12 +18,19 @@ for name, path, W, H, spp, depth, skip in [("cornell", "data/scenes/tungsten/cor
     ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings)
     out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
     st = ctx.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
-    raw = (C.c_ulonglong * 32)()
+    raw = (C.c_ulonglong * 40)()
     assert device.lib().mi355rt_debug_read_counters(ctx._h, raw) == 0
     acc = np.array(list(raw)[2:8], dtype=np.float64)
     print(f"{name}: kernel {st.render_kernel_ms:.2f} ms (stamped build), rays/sample {st.rays / st.samples:.2f}")
     for n, v in zip(NAMES, acc):
         if v: print(f"   {n:38s} {100 * v / acc.sum():6.2f} %")
+    cl = list(raw)[24:34]
+    if sum(cl) and ctx.kernel_variant() in (0, 3):
+        iters = cl[8]                   # wave iterations with at least one lane to shade
+        print(f"   shading step: {iters / (st.rays / 64.0):.2f} wave iterations per 64 rays, {cl[9] / max(iters, 1):.1f} lanes with a ray to produce")
+        for i, n in enumerate(["rough conductor branch", "Lambert-style bounce (cooperative unit ball)", "metal / dielectric branch", "camera ray (fresh path)"]):
+            e, l = cl[2 * i], cl[2 * i + 1]
+            if e: print(f"   {n:46s} runs in {100 * e / max(iters, 1):5.1f} % of the wave iterations at a mean of {l / e:5.1f} lanes")
     blk = list(raw)[8:24]
     if sum(blk):
         rays = st.rays
