@@ -304,14 +304,14 @@ DI bool hit_mesh(cprim_t pr, uint32_t i, const DevNode* __restrict__ nodes, cons
 
 // The HitRecord of the list's winner (hittable.rs:10-27), once per ray.  Lanes of a wave may have different winners, so
 // the primitive record is read per lane here (global loads; L1/L2 resident).
-template <bool HAS_MESH, class C>
+template <bool HAS_MESH, bool SHARED_TAIL = !HAS_MESH, class C>
 DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__ tris, const C& c, f3 ro, f3 rd, Hit& h) {
     const DevPrim* __restrict__ pr = prims + c.idx;
     const uint32_t kind = pr->kind;
     // Mesh-free lists: each kind only says where the hit is and which way its surface faces; HitRecord::set_face_normal
     // (hittable.rs:19-26) then runs once for all lanes of the wave, whatever their winners are (cornell -2.5 %).  With meshes in
     // the list every kind finishes its own record (measured: the shared tail costs the wavefront kernel 3-4 %).
-    constexpr bool shared_tail = !HAS_MESH;
+    constexpr bool shared_tail = SHARED_TAIL;
     if (shared_tail) {
         f3 p = ro + rd * c.t, outward;                                        // sphere.rs:35, plane.rs:40, quad.rs:103
         if (kind == MI355RT_PRIM_QUAD) {                                      // quad.rs:103-131

@@ -176,9 +176,10 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 // pass live = false and can_take = false and are left untouched.
 // Returns false when no lane is live afterwards and no work is left to deal.
 // DEFAULTS: give the per-lane temporaries default values.  The lockstep kernels run without (every value is read only on the
-// path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %); the register allocation of the
-// state-machine / pool / wavefront kernels is better WITH them (wavefront: 38 spilled registers with, 120 without).
-template <uint32_t MATS, bool DEFAULTS = true, class WC>
+// path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %), and since round 3 so does the wavefront
+// kernel (rt_wavefront.h, MI355RT_AB_WF_DEFAULTS); the reference build's state-machine / pool kernels keep them (their other lanes'
+// state must not be touched).  WIDE: Philox on 64-bit products (rt_rng.h).
+template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, class WC>
 DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
@@ -187,7 +188,11 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
     if (DEFAULTS) q0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         f3 term = mk(0.f, 0.f, 0.f); bool fin = false;
+#ifdef MI355RT_AB_NO_SKY
+        if (!hit) { term = mk(P.miss[0], P.miss[1], P.miss[2]); fin = true; }
+#else
         if (!hit) { term = miss_colour(P.sky, P.sky_w, P.sky_h, P.miss, ps.rd); fin = true; }   // renderer.rs:38-63
+#endif
         else {
             q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
             const uint32_t kind = __float_as_uint(q0.x);
@@ -206,7 +211,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
         raw = mk(0.f, 0.f, 1.f); atten = mk(0.f, 0.f, 0.f); emitted = mk(0.f, 0.f, 0.f); side = EPS;
         if (live) {
             if (!fresh) ps.rng.next_event();
-            ps.rng.load_block0();
+            ps.rng.template load_block0<WIDE>();
             if (fresh) {
                 const float u = ((float)ps.px + ps.rng.jitter_u()) / (float)P.width;         // renderer.rs:96
                 const float v = ((float)ps.py + ps.rng.jitter_v()) / (float)P.height;        // renderer.rs:97
@@ -215,11 +220,11 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
                 ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
                 if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
             } else {
-                scattered = scatter_pre<MATS>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
+                scattered = scatter_pre<MATS, WIDE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
             }
         }
         prof.mark(5);
-        const f3 ball = unit_ball_cooperative(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
+        const f3 ball = unit_ball_cooperative<WIDE>(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
         if (live && !fresh) {
             if (scattered) scattered = ball_finish(ball_use, h, ball, fuzz, raw);            // (a fuzzed metal reflection may still be absorbed)
             if (scattered) {
@@ -241,7 +246,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
         // overwritten for all lanes at the end: no conditional updates of loop-carried registers, no copies to merge them.
         f3 n_ro, n_thr; uint32_t n_ri;
         if (!fresh) ps.rng.next_event();
-        ps.rng.load_block0<true>();
+        ps.rng.template load_block0<WIDE>();
         if (live) {
             if (fresh) {
                 const float u = ((float)ps.px + ps.rng.jitter_u()) / (float)P.width;         // renderer.rs:96
@@ -251,12 +256,12 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
                 n_thr = mk(1.f, 1.f, 1.f); n_ri = 0;
                 if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
             } else {
-                scattered = scatter_pre<MATS, true>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
+                scattered = scatter_pre<MATS, WIDE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
             }
         }
         prof.mark(5);
         prof.classes(live && !fresh, live && fresh, __float_as_uint(q0.x));
-        const f3 ball = unit_ball_cooperative<true>(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
+        const f3 ball = unit_ball_cooperative<WIDE>(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
         if (live && !fresh) {
             if (scattered) scattered = ball_finish(ball_use, h, ball, fuzz, raw);            // (a fuzzed metal reflection may still be absorbed)
             if (scattered) {
@@ -334,7 +339,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         Hit h; bool hit = false;                           // h is read only where `hit` says it was written: no default values to copy around
         if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<MATS, false>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false, true>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths

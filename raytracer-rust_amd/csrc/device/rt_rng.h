@@ -15,8 +15,9 @@ DI float u32_to_range11(uint32_t w) { float v12 = __uint_as_float((w >> 9) | 0x3
 // Philox4x32-10: counter-based, no state.  10 x (2 x 32x32->64 multiplies + 4 xor + 2 add).
 // WIDE: one 64-bit product per multiplier -- v_mad_u64_u32 issues like ONE v_mul_hi_u32 (2.1 add slots, tools/microbench/int_mul.hip)
 // and yields both halves, where __umulhi() and `*` written separately compile to two such instructions: 20 instead of 40
-// slow multiplies per call.  The VALU-bound lockstep kernels use it (cornell -6.1 %, veach-mis -2.4 %); the latency-bound
-// wavefront kernel is 2-3 % faster on the two independent multiplies (measured), so it keeps them.  Same bits either way.
+// slow multiplies per call.  The VALU-bound lockstep kernels use it (cornell -6.1 %, veach-mis -2.4 %); the wavefront kernel
+// was 2-3 % faster on the two independent multiplies while its SHADE spilled 50 registers (round 2) and is 1 % faster on the wide
+// form since round 3 (rt_wavefront.h).  Same bits either way.
 template <bool WIDE = false>
 DI void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

@@ -3,6 +3,21 @@
 // inlined device functions, and build.kernel_hash() covers every file of this directory).
 #pragma once
 
+// shade_and_regenerate's form in the wavefront kernel (rt_kernels.hip): without default values and with Philox on 64-bit products,
+// like the lockstep kernels.  Round 2 measured both the other way round (38 spilled registers with defaults, 120 without; the wide
+// multiply 2-3 % slower) -- on a kernel whose SHADE spilled 50 registers.  With the metal's loop gone and the material sets
+//  the allocation has room: semesterbild / teapot 800x600x256 (ms): defaults + narrow 28.45 / 16.88, defaults + wide
+// 28.17 / 16.66, no defaults + narrow 28.17 / 16.83, no defaults + wide 27.91 / 16.62.
+#ifndef MI355RT_AB_WF_DEFAULTS
+#define MI355RT_AB_WF_DEFAULTS false
+#endif
+#ifndef MI355RT_AB_WF_SHARED_TAIL
+#define MI355RT_AB_WF_SHARED_TAIL false                     // A/B: one HitRecord::set_face_normal for all kinds in SHADE's finish_hit (as the mesh-free kernels do)
+#endif
+#ifndef MI355RT_AB_WF_WIDE
+#define MI355RT_AB_WF_WIDE true
+#endif
+
 namespace mi355rt {
 
 // ===================================================================================================
@@ -297,6 +312,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             const bool have = lane < n, fill = lane >= n && lane < n + nf;
             MI355RT_WFCOUNT(3, n + nf);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
+            // (the defaults stay: with the path state and the record left uninitialised for the lanes that hold no slot the same
+            // kernel ran 50 % slower -- 41.5 instead of 27.9 ms on semesterbild)
             PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
             ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
             Cand c; cand_reset(c);
@@ -312,8 +329,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             bool live = have;
             const bool any_hit = have && c.idx != CAND_NONE;
             Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
-            if (any_hit) finish_hit<true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
-            shade_and_regenerate<MATS>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
+            if (any_hit) finish_hit<true, MI355RT_AB_WF_SHARED_TAIL>(P.prims, P.tris, c, ps.ro, ps.rd, h);
+            shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
             if (live) {                                                          // a ray to trace: continuing or freshly generated
                 reinterpret_cast<float4*>(sl)[0] = make_float4(ps.ro.x, ps.ro.y, ps.ro.z, ps.thr.x);
                 reinterpret_cast<float4*>(sl)[1] = make_float4(ps.rd.x, ps.rd.y, ps.rd.z, ps.thr.y);
@@ -448,12 +465,15 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #define MI355RT_OCC_WF 6
 #endif
 #define MI355RT_OCC_WFK __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_WF, MI355RT_OCC_WF)))
+#ifndef MI355RT_AB_WF_NOMETAL_MATS
+#define MI355RT_AB_WF_NOMETAL_MATS MATS_NO_METAL
+#endif
 #ifndef MI355RT_AB_WF_MATS
 #define MI355RT_AB_WF_MATS MATS_ALL
 #endif
 // Entry points: one body per material set (rt_device.h); the opt-in slab test only in the general form.
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MATS>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true, MATS_ALL>(P); }
 
 
