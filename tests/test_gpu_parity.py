@@ -137,10 +137,20 @@ def test_mesh_kernels_equal_the_lockstep_walk(name, native, oracle_mod, abi, kno
                         (R, {"kernel": 5}), (R, {"kernel": 5, "walkers": 9, "trav_min": 1}),                  # walk pool: 4 and 9 walker waves
                         (R, {"kernel": 5, "inline_steps": 0, "pool_patience": 500, "trav_min": 48})):
         knobs(library, **kv)
-        gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(), library=library)
+        try:
+            gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(), library=library)
+        except device.RenderError as e:
+            # A kernel of the reference build reported its watchdog once in round 3's ~150 renders of this loop (which of the eight
+            # configurations was not recorded then; it is now) -- a clean MI355RT_ERR_HIP, never a wrong image.  It is a bit-identity reference, not a product kernel: one retry, and the
+            # case is named if it fails again.  A product-library kernel gets no second chance.
+            if library is None or "watchdog" not in str(e):
+                raise
+            import warnings
+            warnings.warn(f"reference kernel {kv} reported its watchdog once: {e}")
+            gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(), library=library)
         outs.append((gp, gl, st.rays))
-    for gp, gl, rays in outs[1:]:
-        assert np.array_equal(gl.view(np.uint32), outs[0][1].view(np.uint32)) and np.array_equal(gp, outs[0][0]) and rays == outs[0][2]
+    for i, (gp, gl, rays) in enumerate(outs[1:], 1):
+        assert np.array_equal(gl.view(np.uint32), outs[0][1].view(np.uint32)) and np.array_equal(gp, outs[0][0]) and rays == outs[0][2], f"configuration {i}"
     if name == "teapot":
         op, ol, cnt = oracle_mod.render(sc, sc.camera, sc.settings, abi.Options.make())
         assert np.array_equal(outs[0][1].view(np.uint32), ol.view(np.uint32)) and cnt.rays == outs[0][2]
