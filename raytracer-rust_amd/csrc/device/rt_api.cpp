@@ -407,12 +407,22 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     // the kinds a scene does not have are compiled out -- they set the register peak.  The library reads NO environment
     // variables; the diagnostic hook mi355rt_debug_set_knob("kernel", v) may name another variant this library was built with.
     if (has_mesh) ctx->variant = covers(KERNEL_WAVEFRONT_NOMETAL) ? KERNEL_WAVEFRONT_NOMETAL : KERNEL_WAVEFRONT;
-    else ctx->variant = covers(KERNEL_LOCKSTEP_SIMPLE) ? KERNEL_LOCKSTEP_SIMPLE : covers(KERNEL_LOCKSTEP_NOSPEC) ? KERNEL_LOCKSTEP_NOSPEC : KERNEL_LOCKSTEP;
+    else {
+        // Mesh-free lists run on a lockstep kernel -- unless the shading step diverges EXPENSIVELY: a rough conductor (ln, atan, two
+        // sin_cos, the conductor's Fresnel term: ~400 instructions) next to another scattering material.  In lockstep a wave pays that branch
+        // whenever any lane takes it (veach-mis: in 71 % of its iterations, for 6.8 lanes); the wavefront kernel's material-sorted SHADE
+        // passes run it at ~57 lanes: veach-mis 18.30 -> 16.75 ms at 256 spp.  Cheap mixtures (Lambert + metal + dielectric + plastic)
+        // measured 3-7 % FASTER in lockstep (tools/ab_fuzz_scene.py), and so stay there.
+        const bool rough = (scene_mats & MATS_ROUGH) != 0u, other_scatter = (scene_mats & ~(MATS_ROUGH | MATS_TERMINAL)) != 0u;
+        ctx->variant = covers(KERNEL_LOCKSTEP_SIMPLE) ? KERNEL_LOCKSTEP_SIMPLE
+                     : (rough && other_scatter && covers(KERNEL_WAVEFRONT_MESHFREE)) ? KERNEL_WAVEFRONT_MESHFREE
+                     : covers(KERNEL_LOCKSTEP_NOSPEC) ? KERNEL_LOCKSTEP_NOSPEC : KERNEL_LOCKSTEP;
+    }
     if (ctx->forced_variant >= 0) {
         const uint32_t v = (uint32_t)ctx->forced_variant;
-        const bool mesh_free_only = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC;
+        const bool mesh_free_only = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_MESHFREE;
         const bool selectable = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || v == KERNEL_POOL || v == KERNEL_WAVEFRONT ||
-                                v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_NOMETAL;       // (the _FIXAABB forms follow options.flags)
+                                v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_NOMETAL || v == KERNEL_WAVEFRONT_MESHFREE;   // (the _FIXAABB forms follow options.flags)
         const bool ok = render_ctr_variant_built(v) && selectable && covers(v) && !(mesh_free_only && has_mesh) && !(v == KERNEL_POOL && !has_mesh);
         if (ok) ctx->variant = v;
     }

@@ -132,7 +132,8 @@ enum : uint32_t {
     KERNEL_WAVEFRONT_FIXAABB = 8,
     KERNEL_LOCKSTEP_NOSPEC = 9,  // KERNEL_LOCKSTEP without the metal and dielectric branches: 72 VGPRs = 7 waves per SIMD (veach-mis)
     KERNEL_WAVEFRONT_NOMETAL = 10,   // KERNEL_WAVEFRONT without the metal branch (teapot, semesterbild)
-    KERNEL_VARIANTS = 11
+    KERNEL_WAVEFRONT_MESHFREE = 11,  // the wavefront for lists WITHOUT a mesh, no metal / dielectric: material-sorted SHADE passes for scenes whose materials diverge (veach-mis)
+    KERNEL_VARIANTS = 12
 };
 // Material sets (bit k = kind MI355RT_MAT_k may occur) the kernels are instantiated for; set_scene picks, per kernel family, the
 // most pruned instantiation whose set covers the scene's materials.  The branches compiled out set the register peak.
@@ -145,7 +146,8 @@ constexpr uint32_t MATS_ROUGH = MATBIT(MI355RT_MAT_ROUGH_GGX) | MATBIT(MI355RT_M
 constexpr uint32_t MATS_NO_METAL = MATS_ALL & ~MATBIT(MI355RT_MAT_METAL);
 constexpr uint32_t MATS_NO_SPECULAR = MATS_ALL & ~(MATBIT(MI355RT_MAT_METAL) | MATBIT(MI355RT_MAT_DIELECTRIC));
 inline uint32_t mats_of_variant(uint32_t variant) {
-    return variant == KERNEL_LOCKSTEP_SIMPLE ? MATS_LAMBERT : variant == KERNEL_LOCKSTEP_NOSPEC ? MATS_NO_SPECULAR : variant == KERNEL_WAVEFRONT_NOMETAL ? MATS_NO_METAL : MATS_ALL;
+    return variant == KERNEL_LOCKSTEP_SIMPLE ? MATS_LAMBERT : (variant == KERNEL_LOCKSTEP_NOSPEC || variant == KERNEL_WAVEFRONT_MESHFREE) ? MATS_NO_SPECULAR
+         : variant == KERNEL_WAVEFRONT_NOMETAL ? MATS_NO_METAL : MATS_ALL;
 }
 
 struct ResolveParams {
@@ -219,7 +221,7 @@ static_assert(WF_FIXED_WORDS <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budge
 constexpr uint32_t WF_LDS_NODES = MI355RT_WF_LDS_NODES >= 0 ? (uint32_t)MI355RT_WF_LDS_NODES : (WF_LDS_BUDGET_WORDS - WF_FIXED_WORDS) / 8u;    // 32-byte nodes
 static_assert(WF_FIXED_WORDS + 8u * WF_LDS_NODES <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budget (node copy)");
 constexpr uint32_t STATS_WORDS = 40;                         // u64 device counters per render: [0] paths, [1] rays, the rest diagnostic builds only
-inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB || variant == KERNEL_WAVEFRONT_NOMETAL; }
+inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB || variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_MESHFREE; }
 inline uint32_t block_threads_of(uint32_t variant) {
     return is_wavefront(variant) ? BLOCK_THREADS_WF
          : (variant == KERNEL_STATE_MACHINE || variant == KERNEL_STATE_MACHINE_FIXAABB || variant == KERNEL_POOL || variant == KERNEL_POOL_FIXAABB) ? BLOCK_THREADS_SM : BLOCK_THREADS;

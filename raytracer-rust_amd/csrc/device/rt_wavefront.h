@@ -56,7 +56,7 @@ DI uint32_t shade_class(uint32_t kind) {
          : (kind == MI355RT_MAT_ROUGH_GGX || kind == MI355RT_MAT_ROUGH_BECKMANN) ? 2u
          : (kind == MI355RT_MAT_METAL || kind == MI355RT_MAT_DIELECTRIC) ? 3u : 1u;
 }
-constexpr uint32_t WF_LDS_WORDS = WF_FIXED_WORDS + 8u * WF_LDS_NODES;
+constexpr uint32_t WF_PATHS_MESHFREE = 1023;                // 64-byte slots beside the seven rings: 79 936 of the 81 920 bytes
 static_assert(WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "a ring holds every slot number");
 // Slot layout, 5 x 16 bytes (the less a path carries, the more paths fit, and the fill of every pass follows from their number:
 // 960 slots of 36 dwords ran SHADE at 37 of 64 lanes):  q0 ro.xyz thr.x | q1 rd.xyz thr.y | q2 thr.z sidx ray_index cursor(+WALK_DONE) |
@@ -129,8 +129,15 @@ struct WfQueues {
     }
 };
 
-template <bool FIXED_AABB, uint32_t MATS>
+// HAS_MESH = false: the same wavefront for lists without a mesh (picked when the materials of such a scene diverge): no
+// WALK / TOP1 stages, 16-word slots (no walk state), 1 023 of them.
+template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true>
 DI void render_ctr_wavefront(const RenderParams& P) {
+    constexpr uint32_t WF_PATHS = HAS_MESH ? mi355rt::WF_PATHS : WF_PATHS_MESHFREE, WF_SLOT_WORDS = HAS_MESH ? mi355rt::WF_SLOT_WORDS : 16u;
+    constexpr uint32_t WF_FIXED_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
+    constexpr uint32_t WF_LDS_NODES = HAS_MESH ? mi355rt::WF_LDS_NODES : 0u;
+    constexpr uint32_t WF_LDS_WORDS = WF_FIXED_WORDS + 8u * WF_LDS_NODES;
+    static_assert(WF_LDS_WORDS <= WF_LDS_BUDGET_WORDS && WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "wavefront kernel LDS budget / ring size");
     __shared__ __attribute__((aligned(16))) uint32_t s_wf[WF_LDS_WORDS];
     WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + WF_CTRL_WORDS); Q.entry_spins = P.spin_limit_entry;
     uint32_t* const slots = s_wf + WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u;
@@ -193,7 +200,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                     case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ro, rd, EPS, c); break;
                     case MI355RT_PRIM_CUBE:   hit_cube(pr, i, ro, rd, EPS, c); break;
                     default:
-                        if (!walk_done) {
+                        if constexpr (!HAS_MESH) break;                // (the host picks this instantiation for mesh-free lists only)
+                        else if (!walk_done) {
                             MeshTrav mt; mesh_setup(pr, ro, rd, c.t, mt);
                             const uint32_t root = mt.node;
                             mesh_step<FIXED_AABB, WF_LDS_MODE>(n4, lds, lds_count, EPS, mt);       // the root box, here: most rays miss it
@@ -244,7 +252,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
     for (;;) {
         if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[17], 1u); break; }
         if (__hip_atomic_load(&Q.ctrl[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
-        const uint32_t cT1 = Q.count(WQ_TOP1), cW = Q.count(WQ_WALK);
+        const uint32_t cT1 = HAS_MESH ? Q.count(WQ_TOP1) : 0u, cW = HAS_MESH ? Q.count(WQ_WALK) : 0u;
         const uint32_t cS0 = Q.count(WQ_SHADE), cS1 = Q.count(WQ_SHADE + 1u), cS2 = Q.count(WQ_SHADE + 2u), cS3 = Q.count(WQ_SHADE + 3u);
         const uint32_t cS = cS0 + cS1 + cS2 + cS3;
         const uint32_t cF = wc.exhausted() ? 0u : Q.count(WQ_FREE);
@@ -329,7 +337,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             bool live = have;
             const bool any_hit = have && c.idx != CAND_NONE;
             Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
-            if (any_hit) finish_hit<true, MI355RT_AB_WF_SHARED_TAIL>(P.prims, P.tris, c, ps.ro, ps.rd, h);
+            if (any_hit) finish_hit<HAS_MESH, HAS_MESH ? MI355RT_AB_WF_SHARED_TAIL : true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
             shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
             if (live) {                                                          // a ray to trace: continuing or freshly generated
                 reinterpret_cast<float4*>(sl)[0] = make_float4(ps.ro.x, ps.ro.y, ps.ro.z, ps.thr.x);
@@ -350,6 +358,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             continue;
         }
 
+        if constexpr (HAS_MESH) {                                        // (a mesh-free list has only the SHADE stages)
         if (stage == WQ_WALK) {
             // ---- WALK: two rounds of eight box tests + the pending leaves; unfinished walks go round again ----
             const uint32_t n = Q.pop(WQ_WALK, 64u, keep(min(cW, 64u)), lane, 0u, id, failed);
@@ -448,6 +457,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             run_top(have, ro, rd, c, cursor, walk_done, sl, id);
             prof.mark(1);
         }
+        }   // HAS_MESH
     }
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
     if (lane == 0 && P.stats) {
@@ -465,6 +475,9 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #define MI355RT_OCC_WF 6
 #endif
 #define MI355RT_OCC_WFK __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_WF, MI355RT_OCC_WF)))
+#ifndef MI355RT_AB_WF_MESHFREE_MATS
+#define MI355RT_AB_WF_MESHFREE_MATS MATS_NO_SPECULAR
+#endif
 #ifndef MI355RT_AB_WF_NOMETAL_MATS
 #define MI355RT_AB_WF_NOMETAL_MATS MATS_NO_METAL
 #endif
@@ -474,6 +487,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 // Entry points: one body per material set (rt_device.h); the opt-in slab test only in the general form.
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MATS>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_meshfree(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MESHFREE_MATS, false>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true, MATS_ALL>(P); }
 
 

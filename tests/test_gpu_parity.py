@@ -184,8 +184,10 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, knobs):
     op, ol, cnt = oracle_mod.render(sc, sc.camera, sc.settings, abi.Options.make())
     assert np.array_equal(gl.view(np.uint32), ol.reshape(-1).view(np.uint32)) and cnt.rays == rays
 
-    # veach-mis has Lambert + Emissive + Beckmann conductors: no metal, no dielectric -> the general kernel's instantiation without those
-    # two branches (9, 7 waves per SIMD).  It must equal the general kernel (0) bit for bit, and the Lambert-only one must be refused.
+    # veach-mis has Lambert + Emissive + Beckmann conductors: a mesh-free list whose shading step diverges expensively (rough conductor
+    # next to a diffuse material) -> the mesh-free instantiation of the wavefront kernel (11: material-sorted SHADE passes, no metal /
+    # dielectric branch).  It must equal the lockstep kernels -- the general one (0) and the one without metal / dielectric (9) -- bit for
+    # bit, and the Lambert-only kernel (3) must be refused.
     sv = load_for_both("veach", oracle_mod, host, width=80, height=48, spp=4, max_depth=8)
     knobs()
     vv, vp, vl, vr = run(sv)
@@ -193,9 +195,12 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, knobs):
     vv3, _, vl3, _ = run(sv)
     knobs(kernel=0)
     vv0, vp0, vl0, vr0 = run(sv)
-    assert (vv, vv3, vv0) == (9, 9, 0)
+    knobs(kernel=9)
+    vv9, vp9, vl9, vr9 = run(sv)
+    assert (vv, vv3, vv0, vv9) == (11, 11, 0, 9)
     assert np.array_equal(vl.view(np.uint32), vl3.view(np.uint32))
     assert np.array_equal(vl.view(np.uint32), vl0.view(np.uint32)) and np.array_equal(vp, vp0) and vr == vr0
+    assert np.array_equal(vl.view(np.uint32), vl9.view(np.uint32)) and np.array_equal(vp, vp9) and vr == vr9
     # a scene with a metal in it is refused by the pruned instantiation
     from fuzz_scenes import random_scene
     sm = random_scene(abi, host, 31, exact_only=True, n_prims=16, only_kinds=[2, 2, 3, 0, 1, 3, 3, 0, 0, 2, 1, 1])
@@ -204,6 +209,12 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, knobs):
     assert abi.MAT_METAL in kinds or abi.MAT_DIELECTRIC in kinds
     knobs(kernel=9)
     assert run(sm)[0] == 0
+    knobs(kernel=11)
+    assert run(sm)[0] == 0
+    # ... and a mesh-free wavefront kernel is refused for a list with a mesh
+    st = load_for_both("teapot", oracle_mod, host, width=48, height=32, spp=2, max_depth=4)
+    knobs(kernel=11)
+    assert run(st)[0] == 10
 
 
 def test_fixed_wo3_reader_scene_is_bit_identical_to_the_oracle(native, oracle_mod, abi):
