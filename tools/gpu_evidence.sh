@@ -18,6 +18,7 @@ python3 bench.py --pipeline 2 --cpu-seconds 0 > "$OUT/bench_cornell_pipeline2.js
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_cornell.csv" \;
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/stats_teapot" -- python3 "$OLDPWD/bench.py" --workload teapot-800x600x256-d64 --steps 20 --warmup 3 --cpu-seconds 0 > "$OLDPWD/$OUT/stats_teapot.log" 2>&1) || { tail -20 "$OUT/stats_teapot.log"; exit 1; }
 find "$OUT/stats_teapot" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_teapot.csv" \;
+python3 tools/ab_fuzz_scene.py 31 32 33 > "$OUT/ab_fuzz_scene.txt" 2>&1 || { tail -5 "$OUT/ab_fuzz_scene.txt"; exit 1; }
 python3 tools/stamps.py > "$OUT/stamps.txt" 2>&1 || { tail -5 "$OUT/stamps.txt"; exit 1; }
 python3 bench.py --workload cornell-box-400x300x16-d4 --steps 50 --warmup 5 > "$OUT/bench_cornell-box-400x300x16-d4.json" 2> "$OUT/bench_cfg1.err" || { cat "$OUT/bench_cfg1.err"; exit 1; }
 cat "$OUT/bench_cornell-box-800x600x256-d30.json"
