@@ -222,8 +222,16 @@ constexpr uint32_t WF_LDS_NODES = MI355RT_WF_LDS_NODES >= 0 ? (uint32_t)MI355RT_
 static_assert(WF_FIXED_WORDS + 8u * WF_LDS_NODES <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budget (node copy)");
 constexpr uint32_t STATS_WORDS = 40;                         // u64 device counters per render: [0] paths, [1] rays, the rest diagnostic builds only
 inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB || variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_MESHFREE; }
+// The mesh-free form runs 2 x 16 waves per CU at 64 VGPRs (8 per SIMD): veach-mis 16.71 -> 16.09 ms; the forms with the BVH walk lose a third
+// there (42 spilled registers).  Waves per workgroup must be a multiple of 4: a workgroup's waves are dealt round-robin over the CU's
+// four SIMDs, and with 10, 13 or 14 of them the second workgroup no longer fits the per-SIMD wave budget (measured: +40 %; this also explains
+// round 2's "2 x 10 waves at 96 VGPRs" result).
+#ifndef MI355RT_WF_THREADS_MESHFREE
+#define MI355RT_WF_THREADS_MESHFREE 1024
+#endif
+constexpr uint32_t BLOCK_THREADS_WF_MESHFREE = MI355RT_WF_THREADS_MESHFREE;
 inline uint32_t block_threads_of(uint32_t variant) {
-    return is_wavefront(variant) ? BLOCK_THREADS_WF
+    return variant == KERNEL_WAVEFRONT_MESHFREE ? BLOCK_THREADS_WF_MESHFREE : is_wavefront(variant) ? BLOCK_THREADS_WF
          : (variant == KERNEL_STATE_MACHINE || variant == KERNEL_STATE_MACHINE_FIXAABB || variant == KERNEL_POOL || variant == KERNEL_POOL_FIXAABB) ? BLOCK_THREADS_SM : BLOCK_THREADS;
 }
 

@@ -535,7 +535,7 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
         case KERNEL_LOCKSTEP_MESH:   hipLaunchKernelGGL(k_render_ctr_mesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_SIMPLE: hipLaunchKernelGGL(k_render_ctr_simple, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_NOSPEC: hipLaunchKernelGGL(k_render_ctr_nospec, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
-        case KERNEL_WAVEFRONT_MESHFREE: hipLaunchKernelGGL(k_render_ctr_wf_meshfree, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
+        case KERNEL_WAVEFRONT_MESHFREE: hipLaunchKernelGGL(k_render_ctr_wf_meshfree, dim3(grid_blocks), dim3(BLOCK_THREADS_WF_MESHFREE), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_NOMETAL: hipLaunchKernelGGL(k_render_ctr_wf_nometal, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT:       hipLaunchKernelGGL(k_render_ctr_wf, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_FIXAABB: hipLaunchKernelGGL(k_render_ctr_wf_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;

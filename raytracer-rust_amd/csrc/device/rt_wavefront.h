@@ -581,7 +581,10 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 // Entry points: one body per material set (rt_device.h); the opt-in slab test only in the general form.
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MATS>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS, true, MI355RT_AB_WF_COMPACT>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_meshfree(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MESHFREE_MATS, false>(P); }
+#ifndef MI355RT_OCC_WF_MESHFREE
+#define MI355RT_OCC_WF_MESHFREE 8
+#endif
+__global__ void __launch_bounds__(BLOCK_THREADS_WF_MESHFREE) __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_WF_MESHFREE, MI355RT_OCC_WF_MESHFREE))) k_render_ctr_wf_meshfree(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MESHFREE_MATS, false>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true, MATS_ALL>(P); }
 
 
