@@ -525,6 +525,9 @@ void mi355rt_context_destroy(mi355rt_context* ctx) {
     delete ctx;
 }
 
+static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint32_t s0, uint32_t s1, void* d_accum,
+                          void* d_out_packed, void* d_out_linear, void* hip_stream, mi355rt_stats* stats);
+
 int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, const mi355rt_camera* camera,
                               const mi355rt_settings* settings) {
     if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
@@ -537,6 +540,29 @@ int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, 
     std::memcpy(&ctx->cam, camera, sizeof(DevCamera));
     ctx->settings = *settings;
     ctx->have_scene = true;
+    // The materials only say that the mesh-free wavefront kernel MAY pay (a rough conductor next to another scattering material).  Whether
+    // it does depends on how much the paths scatter: veach-mis bounces 1.5 times per path and gains 13 %; a scene of the same materials that is
+    // mostly sky (1.1 rays per path) has nothing to sort and lost 14 % to the queues (profiles/r03_ab_meshfree_wavefront_fuzz_scenes.txt).
+    // A probe decides: the same view at 64 pixels across, 4 samples per pixel, on the lockstep kernel -- deterministic (counter RNG), a
+    // fraction of a millisecond -- and the wavefront form is kept when a path traces at least PROBE_RAYS_PER_PATH rays.
+    if (ctx->variant == KERNEL_WAVEFRONT_MESHFREE && ctx->forced_variant < 0) {
+        constexpr double PROBE_RAYS_PER_PATH = 1.6;       // veach-mis with max_bounces 1 / 2 / 3 / 16: 1.00 / 1.90 / 2.20 / 2.48 rays per path, wavefront +5.5 / -4.0 / -6.5 / -10.2 %
+                                                          // against lockstep (profiles/r03_probe_calibration.txt): break-even near 1.5
+        const mi355rt_settings full = ctx->settings;
+        mi355rt_settings probe = full;
+        probe.width = std::min(full.width, 64u);
+        probe.height = std::max(1u, std::min(full.height, (uint32_t)((uint64_t)probe.width * full.height / full.width)));
+        probe.samples_per_pixel = std::min(full.samples_per_pixel, 4u);
+        uint32_t* d_tmp = nullptr;
+        if (hipMalloc((void**)&d_tmp, (size_t)probe.width * probe.height * 4) != hipSuccess) { ctx->have_scene = false; return fail(MI355RT_ERR_OOM, "hipMalloc(probe)"); }
+        ctx->settings = probe; ctx->variant = KERNEL_LOCKSTEP_NOSPEC;
+        mi355rt_stats st{};
+        rc = render_samples(ctx, nullptr, 0, probe.samples_per_pixel, nullptr, d_tmp, nullptr, nullptr, &st);
+        (void)hipFree(d_tmp);
+        ctx->settings = full; ctx->rows_valid = false;
+        if (rc) { ctx->have_scene = false; return rc; }
+        ctx->variant = ((double)st.rays >= PROBE_RAYS_PER_PATH * (double)std::max<uint64_t>(st.samples, 1)) ? KERNEL_WAVEFRONT_MESHFREE : KERNEL_LOCKSTEP_NOSPEC;
+    }
     return MI355RT_OK;
 }
 

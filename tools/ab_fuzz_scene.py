@@ -25,5 +25,6 @@ for seed in [int(a) for a in sys.argv[1:]] or [31, 32]:
                 s = c.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
                 if r: t.append(s.render_kernel_ms)
             res[name] = (c.kernel_variant(), statistics.median(t), int(out.to(torch.int64).sum().item()))
+            rps = s.rays / max(s.samples, 1)
             c.close()
-        print(f"seed {seed} {label}: " + "  |  ".join(f"{n}: variant {v} {ms:.3f} ms" for n, (v, ms, _) in res.items()) + ("  checksums equal" if len({x[2] for x in res.values()}) == 1 else "  CHECKSUMS DIFFER"), flush=True)
+        print(f"seed {seed} {label} ({rps:.2f} rays per path): " + "  |  ".join(f"{n}: variant {v} {ms:.3f} ms" for n, (v, ms, _) in res.items()) + ("  checksums equal" if len({x[2] for x in res.values()}) == 1 else "  CHECKSUMS DIFFER"), flush=True)
