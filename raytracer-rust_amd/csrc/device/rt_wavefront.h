@@ -8,6 +8,12 @@
 // multiply 2-3 % slower) -- on a kernel whose SHADE spilled 50 registers.  With the metal's loop gone and the material sets
 //  the allocation has room: semesterbild / teapot 800x600x256 (ms): defaults + narrow 28.45 / 16.88, defaults + wide
 // 28.17 / 16.66, no defaults + narrow 28.17 / 16.83, no defaults + wide 27.91 / 16.62.
+#ifndef MI355RT_WF_PRIO_SCHED
+#define MI355RT_WF_PRIO_SCHED 2                             // wave priority while a wave chooses its stage and pops (see the loop head)
+#endif
+#ifndef MI355RT_WF_PRIO_WALK
+#define MI355RT_WF_PRIO_WALK 3                              // ... and inside a WALK pass
+#endif
 #ifndef MI355RT_AB_WF_DEFAULTS
 #define MI355RT_AB_WF_DEFAULTS false
 #endif
@@ -350,9 +356,17 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         uint32_t cls = 0u;
         if (have && !to_walk && c.idx != CAND_NONE) cls = shade_class(P.mats[P.prims[c.idx].material].kind);
         MI355RT_WFCOUNT(2, (uint32_t)__popcll(__ballot(have && to_walk)));
+        __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_SCHED);                     // the pushes are LDS round trips again
         Q.push_each(have, to_walk ? (uint32_t)WQ_WALK : WQ_SHADE + cls, id, lane, failed);
     };
     for (;;) {
+        // Wave priority (s_setprio): the stage choice and the pop are a chain of dependent LDS round trips with a handful of instructions
+        // between them, and a WALK pass is a chain of node loads with ~35 instructions per link -- waves in these phases should get the
+        // issue port the moment their data is back, the long arithmetic of SHADE / TOP fills the gaps.  Priority 2 while choosing and
+        // popping and pushing, 3 in WALK, 0 in the arithmetic of SHADE and TOP: semesterbild 28.13 -> 27.60 -> 27.33 ms, teapot 16.74 -> 16.64 -> 16.42,
+        // veach-mis 16.14 -> 16.01 -> 15.84
+        // (profiles/r03_ab_wavefront_wave_priority.txt; WALK alone -1.4 / -0.3 / 0 %, TOP1 raised as well: no better).
+        __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_SCHED);
         if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[17], 1u); break; }
         if (__hip_atomic_load(&Q.ctrl[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
         const uint32_t cT1 = HAS_MESH ? Q.count(WQ_TOP1) : 0u, cW = HAS_MESH ? Q.count(WQ_WALK) : 0u;
@@ -433,6 +447,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 start_path(P, ps.sidx, ps.rng, ps.px, ps.py);                   // the RNG key is a function of the sample index
                 ps.rng.ray = ps.ray_index;
             }
+            __builtin_amdgcn_s_setprio(0);                                       // (the slot is loaded: from here on the pass is arithmetic)
             bool live = have;
             const bool any_hit = have && c.idx != CAND_NONE;
             Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
@@ -459,6 +474,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             const uint32_t n = Q.pop(WQ_WALK, 64u, keep(min(cW, 64u)), lane, 0u, id, failed);
             if (n == 0u || __ballot(failed) != 0ull) continue;
             const bool have = lane < n;
+            __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_WALK);
             MI355RT_WFCOUNT(0, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
             MeshTrav m; m.ro = mk(0, 0, 0); m.rd = mk(0, 0, 1); m.ix = m.iy = m.iz = 0.f; m.len_raw = 0.f; m.node = NODE_END; m.best_t = 0.f;
@@ -521,6 +537,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             MI355RT_WFCOUNT(6, (uint32_t)__popcll(__ballot(have && m.leaf_b == 0u && m.node == NODE_END)));     // walks finished per WALK pass
             const bool done = have && m.leaf_b == 0u && m.node == NODE_END;        // (a pass always ends with its pending leaves tested: leaf_b == 0)
             if (have) { WalkRec w; w.node = m.node; w.best_t = m.best_t; w.best_tri = m.best_tri; Slot::store_walk(sl, w, done, wkeep); }
+            __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_SCHED);
             Q.push(WQ_WALK, have && !done, id, lane, failed);
             prof.mark(0);
             // (Letting the finished walks go on with the rest of the list in this pass -- the WALK -> TOP1 counterpart of the fused
@@ -534,6 +551,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             const uint32_t n = Q.pop(WQ_TOP1, 64u, keep(min(cT1, 64u)), lane, 0u, id, failed);
             if (n == 0u || __ballot(failed) != 0ull) continue;
             const bool have = lane < n;
+            __builtin_amdgcn_s_setprio(0);
             MI355RT_WFCOUNT(1, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
             f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
