@@ -178,8 +178,9 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 // DEFAULTS: give the per-lane temporaries default values.  The lockstep kernels run without (every value is read only on the
 // path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %), and since round 3 so does the wavefront
 // kernel (rt_wavefront.h, MI355RT_AB_WF_DEFAULTS); the reference build's state-machine / pool kernels keep them (their other lanes'
-// state must not be touched).  WIDE: Philox on 64-bit products (rt_rng.h).
-template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, class WC>
+// state must not be touched).  WIDE: Philox on 64-bit products (rt_rng.h).  DROP_PRIO: lower the wave's priority to 0 once the
+// fresh samples are dealt (the caller raised it for the memory-bound half of the iteration).
+template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, class WC>
 DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
@@ -204,6 +205,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
     prof.mark(2);
     bool fresh = false;
     if (wc.deal(P, can_take && !live, lane, ps.sidx)) { start_path(P, ps.sidx, ps.rng, ps.px, ps.py); fresh = true; live = true; ++n_paths; }
+    if constexpr (DROP_PRIO) __builtin_amdgcn_s_setprio(0);                               // the lockstep kernels' arithmetic half (see render_ctr_lockstep)
     if (__ballot(live) == 0ull) return !wc.exhausted();
     uint32_t ball_use = BALL_NONE; bool scattered = false;
     f3 raw, atten, emitted; float side, fuzz = 0.f;  // written by the branch a lane takes below, read only on that lane's own path
@@ -337,9 +339,15 @@ DI void render_ctr_lockstep(const RenderParams& P) {
 #endif
     for (;;) {
         Hit h; bool hit = false;                           // h is read only where `hit` says it was written: no default values to copy around
+        // Wave priority by phase (round 3; profiles/r03_ab_lockstep_priority.txt): the half of an iteration that waits on memory -- the
+        // list walk's primitive reads, the material read, the radiance store and the work cursor's atomic -- runs at priority 1, the
+        // arithmetic half (Philox, BSDF, the cooperative unit-ball draw, the next ray) at 0, so a SIMD's issue slots go first to the
+        // wave whose loads can then be in flight under the others' arithmetic.  cornell 16.49 -> 15.82 ms, veach-mis on these kernels -1.7 %;
+        // priority 2 or 3 measure the same; keeping it through Philox (15.96) or only over the walk (16.10-16.17) gains less.
+        __builtin_amdgcn_s_setprio(1);
         if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<MATS, false, true>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false, true, true>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths

@@ -14,6 +14,9 @@
 #ifndef MI355RT_WF_PRIO_WALK
 #define MI355RT_WF_PRIO_WALK 3                              // ... and inside a WALK pass
 #endif
+#ifndef MI355RT_WF_PRIO_TOP
+#define MI355RT_WF_PRIO_TOP 1                               // ... and over the top-level list (primitive reads); 0 in SHADE's arithmetic
+#endif
 #ifndef MI355RT_AB_WF_DEFAULTS
 #define MI355RT_AB_WF_DEFAULTS false
 #endif
@@ -365,7 +368,10 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         // issue port the moment their data is back, the long arithmetic of SHADE / TOP fills the gaps.  Priority 2 while choosing and
         // popping and pushing, 3 in WALK, 0 in the arithmetic of SHADE and TOP: semesterbild 28.13 -> 27.60 -> 27.33 ms, teapot 16.74 -> 16.64 -> 16.42,
         // veach-mis 16.14 -> 16.01 -> 15.84
-        // (profiles/r03_ab_wavefront_wave_priority.txt; WALK alone -1.4 / -0.3 / 0 %, TOP1 raised as well: no better).
+        // (profiles/r03_ab_wavefront_wave_priority.txt; WALK alone -1.4 / -0.3 / 0 %, TOP1 raised to 2 as well: no better).
+        // Second pass, after the same idea paid 4 % in the lockstep kernels: SHADE keeps the raised priority until its fresh samples are
+        // dealt (material read, radiance store, cursor atomic), and the top-level list runs at 1 rather than 0:
+        // semesterbild 27.36 -> 27.25, teapot 16.44 -> 16.34, veach-mis 15.86 -> 15.66 (profiles/r03_ab_wavefront_wave_priority2.txt).
         __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_SCHED);
         if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[17], 1u); break; }
         if (__hip_atomic_load(&Q.ctrl[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
@@ -447,12 +453,13 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 start_path(P, ps.sidx, ps.rng, ps.px, ps.py);                   // the RNG key is a function of the sample index
                 ps.rng.ray = ps.ray_index;
             }
-            __builtin_amdgcn_s_setprio(0);                                       // (the slot is loaded: from here on the pass is arithmetic)
             bool live = have;
             const bool any_hit = have && c.idx != CAND_NONE;
             Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
             if (any_hit) finish_hit<HAS_MESH, HAS_MESH ? MI355RT_AB_WF_SHARED_TAIL : true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
-            shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
+            // (the priority stays raised through the material read, the radiance store and the work cursor's atomic: shade_and_regenerate
+            // drops it to 0 where the arithmetic starts, DROP_PRIO; the list walk below reads primitives again and runs at PRIO_TOP)
+            shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
             if (live) Slot::store_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index);    // a ray to trace: continuing or freshly generated
             const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
             if (lane == 0 && born != died) atomicAdd(&Q.ctrl[16], (uint32_t)(born - died));
@@ -461,6 +468,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             // on with TOP for its live lanes: as homogeneous as a pass over a queue of such rays and at least as full, minus one queue
             // round trip per ray (there was a TOP0 queue: semesterbild 9.73 -> 9.08 ms, teapot 6.49 -> 6.17 ms at 64 spp without it).
             prof.mark(4);
+            __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_TOP);
             {   Cand c0; cand_reset(c0);
                 WalkRec w0; w0.node = NODE_END; w0.best_t = 0.f; w0.best_tri = 0xFFFFFFFFu;
                 run_top((have || fill) && live, ps.ro, ps.rd, c0, 0u, false, ps.ray_index, w0, sl, id); }
@@ -551,7 +559,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             const uint32_t n = Q.pop(WQ_TOP1, 64u, keep(min(cT1, 64u)), lane, 0u, id, failed);
             if (n == 0u || __ballot(failed) != 0ull) continue;
             const bool have = lane < n;
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_TOP);
             MI355RT_WFCOUNT(1, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
             f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
