@@ -340,6 +340,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         if (p.kind >= MI355RT_PRIM_KIND_COUNT) return fail(MI355RT_ERR_INVALID, "primitive kind");
         if (p.material >= sc->n_materials) return fail(MI355RT_ERR_INVALID, "primitive material index");
         d.kind = p.kind; d.material = p.material;
+        std::memcpy(d.mat0, &sc->materials[p.material], 16);      // kind + albedo, beside the geometry (rt_device.h)
         // The reference cannot render a sphere of |radius| < 1e-4: sphere.rs:38 divides by the radius with `Vec3 / f32`, which panics
         // below EPSILON (vec3.rs:120-122) the first time the sphere is hit.  Refused here rather than rendered.
         if (p.kind == MI355RT_PRIM_SPHERE && std::fabs(p.data[3]) < 1e-4f)

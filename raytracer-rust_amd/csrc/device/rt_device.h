@@ -24,7 +24,7 @@
 
 namespace mi355rt {
 
-struct DevPrim {                 // 56 words = 224 B
+struct DevPrim {                 // 60 words = 240 B
     uint32_t kind, material, node_begin, run_end;    // node_begin: root node of a MI355RT_PRIM_MESH; run_end: list index one past the
                                                      // run of consecutive primitives of this kind that this one belongs to (> own index)
     // sphere: c[3], r | plane: p1[3], n[3] | quad: base, e0, e1, n, d, inv0, inv1 (15)
@@ -32,8 +32,10 @@ struct DevPrim {                 // 56 words = 224 B
     //              zd[3] = w2o.w_axis.xyz * 0.0f, zn[3] = {w2o[3], w2o[7], w2o[11]} * 0.0f,
     //              cube only: d[34..51] = the 6 possible world normals normalized(w2o^T * (+-e_k, 0)), k = x,y,z, + then -
     float d[52];
+    float mat0[4];                                   // a copy of the first 16 bytes of the primitive's material record (kind, albedo):
+                                                     // the hit record and the head of its material arrive with ONE memory round trip (finish_hit)
 };
-static_assert(sizeof(DevPrim) == 224, "DevPrim must stay 16-byte granular");
+static_assert(sizeof(DevPrim) == 240, "DevPrim must stay 16-byte granular");
 
 struct DevMat {                  // 64 B, same field order as mi355rt_material
     uint32_t kind; float albedo[3];

@@ -14,7 +14,12 @@ namespace mi355rt {
 // reason: the compiler keeps a loop-carried record in two register sets and copies it at every nesting level of every
 // primitive test -- 24-33 v_mov per quad, a third of its instructions; the copies scale with the size of the state.
 // ---------------------------------------------------------------------------------------------------
-struct Hit { float t; f3 p; f3 n; uint32_t mat_ff; };            // the finished record; `mat_ff` = material | front_face << 31
+// `q0` = the first 16 bytes of the hit material (kind, albedo), read from the copy in the primitive record (DevPrim.mat0) together
+// with the record itself -- the kernels of mesh-free lists only (hit_carries_q0): there the material read no longer waits for the
+// record read (cornell 15.85 -> 15.62 ms).  The kernels with the BVH walk have no registers to carry it (teapot +3.5 %) and read
+// the material record after the hit record as before (profiles/r03_ab_material_head_in_primitive.txt).
+constexpr bool hit_carries_q0(bool has_mesh) { return !has_mesh; }
+struct Hit { float t; f3 p; f3 n; uint32_t mat_ff; float4 q0; };            // the finished record; `mat_ff` = material | front_face << 31
 constexpr uint32_t CAND_NONE = 0xFFFFFFFFu;
 struct Cand {
     float t;            // closest hit distance so far (world), +inf while idx == CAND_NONE
@@ -308,6 +313,7 @@ template <bool HAS_MESH, bool SHARED_TAIL = !HAS_MESH, class C>
 DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__ tris, const C& c, f3 ro, f3 rd, Hit& h) {
     const DevPrim* __restrict__ pr = prims + c.idx;
     const uint32_t kind = pr->kind;
+    if constexpr (hit_carries_q0(HAS_MESH)) h.q0 = *reinterpret_cast<const float4*>(pr->mat0);
     // Mesh-free lists: each kind only says where the hit is and which way its surface faces; HitRecord::set_face_normal
     // (hittable.rs:19-26) then runs once for all lanes of the wave, whatever their winners are (cornell -2.5 %).  With meshes in
     // the list every kind finishes its own record (measured: the shared tail costs the wavefront kernel 3-4 %).
@@ -347,6 +353,8 @@ DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__
         }
     }
 }
+
+DI uint32_t prim_material_kind(const RenderParams& P, uint32_t idx) { return __float_as_uint(P.prims[idx].mat0[0]); }   // one read, not two dependent ones
 
 // hittable.rs:45-58 -- HittableList::hit with t_min = EPSILON, t_max = INFINITY (renderer.rs:24)
 template <bool HAS_MESH, class C>

@@ -179,8 +179,8 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 // path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %), and since round 3 so does the wavefront
 // kernel (rt_wavefront.h, MI355RT_AB_WF_DEFAULTS); the reference build's state-machine / pool kernels keep them (their other lanes'
 // state must not be touched).  WIDE: Philox on 64-bit products (rt_rng.h).  DROP_PRIO: lower the wave's priority to 0 once the
-// fresh samples are dealt (the caller raised it for the memory-bound half of the iteration).
-template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, class WC>
+// fresh samples are dealt (the caller raised it for the memory-bound half of the iteration).  Q0_IN_HIT: see struct Hit.
+template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, class WC>
 DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
@@ -195,7 +195,8 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
         if (!hit) { term = miss_colour(P.sky, P.sky_w, P.sky_h, P.miss, ps.rd); fin = true; }   // renderer.rs:38-63
 #endif
         else {
-            q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
+            if constexpr (Q0_IN_HIT) q0 = h.q0;                                              // (finish_hit read it with the hit record)
+            else q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
             const uint32_t kind = __float_as_uint(q0.x);
             if (kind == MI355RT_MAT_EMISSIVE) { term = mk(q0.y, q0.z, q0.w); fin = true; }   // scatter -> None, emitted = colour
             else if (kind == MI355RT_MAT_NULL) fin = true;
@@ -347,7 +348,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         __builtin_amdgcn_s_setprio(1);
         if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<MATS, false, true, true>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false, true, true, hit_carries_q0(HAS_MESH)>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths
