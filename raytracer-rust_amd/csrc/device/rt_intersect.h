@@ -15,10 +15,10 @@ namespace mi355rt {
 // primitive test -- 24-33 v_mov per quad, a third of its instructions; the copies scale with the size of the state.
 // ---------------------------------------------------------------------------------------------------
 // `q0` = the first 16 bytes of the hit material (kind, albedo), read from the copy in the primitive record (DevPrim.mat0) together
-// with the record itself -- the kernels of mesh-free lists only (hit_carries_q0): there the material read no longer waits for the
-// record read (cornell 15.85 -> 15.62 ms).  The kernels with the BVH walk have no registers to carry it (teapot +3.5 %) and read
+// with the record itself -- the lockstep kernels of mesh-free lists only (finish_hit's CARRY_Q0): there the material read no longer
+// waits for the record read (cornell 15.85 -> 15.62 ms).  The wavefront kernels have no registers to carry it (with the BVH walk:
+// teapot +3.5 %; mesh-free at 64 VGPRs: 18 -> 33 spilled registers, veach-mis -0.2 % of time for 2.2x the HBM bytes) and read
 // the material record after the hit record as before (profiles/r03_ab_material_head_in_primitive.txt).
-constexpr bool hit_carries_q0(bool has_mesh) { return !has_mesh; }
 struct Hit { float t; f3 p; f3 n; uint32_t mat_ff; float4 q0; };            // the finished record; `mat_ff` = material | front_face << 31
 constexpr uint32_t CAND_NONE = 0xFFFFFFFFu;
 struct Cand {
@@ -309,11 +309,11 @@ DI bool hit_mesh(cprim_t pr, uint32_t i, const DevNode* __restrict__ nodes, cons
 
 // The HitRecord of the list's winner (hittable.rs:10-27), once per ray.  Lanes of a wave may have different winners, so
 // the primitive record is read per lane here (global loads; L1/L2 resident).
-template <bool HAS_MESH, bool SHARED_TAIL = !HAS_MESH, class C>
+template <bool HAS_MESH, bool SHARED_TAIL = !HAS_MESH, bool CARRY_Q0 = false, class C>
 DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__ tris, const C& c, f3 ro, f3 rd, Hit& h) {
     const DevPrim* __restrict__ pr = prims + c.idx;
     const uint32_t kind = pr->kind;
-    if constexpr (hit_carries_q0(HAS_MESH)) h.q0 = *reinterpret_cast<const float4*>(pr->mat0);
+    if constexpr (CARRY_Q0) h.q0 = *reinterpret_cast<const float4*>(pr->mat0);
     // Mesh-free lists: each kind only says where the hit is and which way its surface faces; HitRecord::set_face_normal
     // (hittable.rs:19-26) then runs once for all lanes of the wave, whatever their winners are (cornell -2.5 %).  With meshes in
     // the list every kind finishes its own record (measured: the shared tail costs the wavefront kernel 3-4 %).
@@ -385,7 +385,7 @@ DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
     typename std::conditional<CARRY_PO && !HAS_MESH, CandP, Cand>::type c; cand_reset(c);
     walk_list<HAS_MESH>(prims, n_prims, nodes, tris, ro, rd, c);
     if (c.idx == CAND_NONE) return false;
-    finish_hit<HAS_MESH>((const DevPrim*)prims, tris, c, ro, rd, best);
+    finish_hit<HAS_MESH, !HAS_MESH, !HAS_MESH>((const DevPrim*)prims, tris, c, ro, rd, best);          // (the lockstep kernels' entry: q0 rides along when there is no mesh)
     return true;
 }
 

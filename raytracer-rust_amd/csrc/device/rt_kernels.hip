@@ -348,7 +348,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         __builtin_amdgcn_s_setprio(1);
         if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<MATS, false, true, true, hit_carries_q0(HAS_MESH)>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths
