@@ -70,6 +70,8 @@ def lib():
         L.oracle_scatter_ctr.argtypes = [C.POINTER(abi.Material), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_void_p]
+        L.oracle_sort_paths.restype = None
+        L.oracle_sort_paths.argtypes = [C.POINTER(C.c_uint64), C.c_int]
         L.oracle_bvh_dump.restype = C.c_int
         L.oracle_bvh_dump.argtypes = [C.POINTER(abi.Triangle), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -123,6 +125,18 @@ def scene_hit(scene, origin, direction):
     if rc < 0:
         raise RuntimeError(f"oracle_scene_hit failed: {rc}")
     return (rc == 1), out
+
+
+SORT_PATHS = ("calls", "insertion_only", "run_ascending", "run_descending", "quicksort", "small_no_merge", "sort9", "sort13", "merge", "merge_odd",
+              "median3", "median3_rec", "partition_lt", "partition_le_ancestor", "heapsort")
+
+
+def sort_paths(reset=False):
+    """Branch counters of the oracle's sort_unstable_by restatement since the last reset (rust_sort_unstable.hpp g_paths)."""
+    L = lib()
+    out = (C.c_uint64 * len(SORT_PATHS))()
+    L.oracle_sort_paths(out, 1 if reset else 0)
+    return dict(zip(SORT_PATHS, [int(v) for v in out]))
 
 
 def bvh_dump(triangles):

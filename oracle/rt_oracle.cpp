@@ -1197,6 +1197,10 @@ static void dump_rec(const BVHNode* n, uint32_t depth, float* bounds, uint32_t* 
     dump_rec(n->left.get(), depth + 1, bounds, info, leaf_ids, ni, li);
     dump_rec(n->right.get(), depth + 1, bounds, info, leaf_ids, ni, li);
 }
+// Branch counters of the sort restatement (rust_sort_unstable.hpp g_paths): out[rustsort::P_COUNT]; reset != 0 clears them afterwards.
+void oracle_sort_paths(uint64_t* out, int reset) {
+    for (int i = 0; i < rustsort::P_COUNT; ++i) { if (out) out[i] = rustsort::g_paths[i]; if (reset) rustsort::g_paths[i] = 0; }
+}
 int oracle_bvh_dump(const mi355rt_triangle* tris_in, uint32_t n, float* bounds, uint32_t* info, uint32_t* leaf_ids,
                     uint32_t* n_nodes_out, uint32_t* n_leaf_ids_out, uint32_t* max_depth_out) {
     if (!tris_in || n == 0) return MI355RT_ERR_INVALID;

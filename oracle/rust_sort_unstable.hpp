@@ -15,14 +15,21 @@
 //   the ancestor pivot partitions by <=; partition = swap pivot to front, cyclic Lomuto over the rest, swap pivot to num_lt;
 //   heapsort when the limit runs out.
 // Evidence that the restatement is the reference's sort: with it the oracle's replay of the reference stream matches the
-// reference's own committed render docs/semesterbild.png with NO pixel further than 20/255 and 77.7 % of the pixels exact (79.4 % with the f32 quaternion of the loaders)
-// (std::stable_sort: 0.15 % of the pixels > 20 -- whole letter faces -- and 60.5 % exact); tests/test_oracle_golden.py.
+// reference's own committed render docs/semesterbild.png bit for bit, all 480 000 pixels (std::stable_sort instead: whole letter
+// faces differ); tests/test_oracle_golden.py.  tests/test_bvh.py lists which branches of the algorithm that mesh's build goes
+// through (g_paths below) -- those are pinned by the reference's render, the others only by this restatement.
 #pragma once
 #include <cstddef>
 #include <cstdint>
 #include <utility>
 #include <vector>
 namespace rustsort {
+// Which branches of the algorithm a build went through (test infrastructure: tests/test_bvh.py reports which of them the BVH of the
+// reference's own golden-pinned mesh exercises, i.e. which are held by docs/semesterbild.png and which only by this restatement).
+enum Path { P_CALLS, P_INSERTION_ONLY, P_RUN_ASCENDING, P_RUN_DESCENDING, P_QUICKSORT, P_SMALL_NO_MERGE, P_SORT9, P_SORT13, P_MERGE, P_MERGE_ODD,
+            P_MEDIAN3, P_MEDIAN3_REC, P_PARTITION_LT, P_PARTITION_LE_ANCESTOR, P_HEAPSORT, P_COUNT };
+inline uint64_t g_paths[P_COUNT] = {};
+inline void hit(Path p) { ++g_paths[p]; }
 template <class T, class F> void insertion_sort_shift_left(T* v, size_t len, size_t offset, F& is_less) {
     for (size_t i = offset; i < len; ++i) {                       // insert_tail(v[..=i])
         if (is_less(v[i], v[i - 1])) {
@@ -50,7 +57,7 @@ template <class T, class F> void bidirectional_merge(const T* src, size_t len, T
         { const bool is_l = !is_less(*right, *left); *d++ = is_l ? *left : *right; right += !is_l; left += is_l; }                    // merge_up
         { const bool is_l = !is_less(*right_rev, *left_rev); *d_rev-- = is_l ? *right_rev : *left_rev; right_rev -= is_l; left_rev -= !is_l; }   // merge_down
     }
-    if (len % 2 != 0) { const bool left_nonempty = left < left_rev + 1; *d = left_nonempty ? *left : *right; }
+    if (len % 2 != 0) { hit(P_MERGE_ODD); const bool left_nonempty = left < left_rev + 1; *d = left_nonempty ? *left : *right; }
 }
 template <class T, class F> void small_sort_network(T* v, size_t len, F& is_less) {
     if (len < 2) return;
@@ -58,14 +65,15 @@ template <class T, class F> void small_sort_network(T* v, size_t len, F& is_less
     T* region = v; size_t rlen = no_merge ? len : half;
     for (;;) {
         size_t presorted = 1;
-        if (rlen >= 13) { sort13_optimal(region, is_less); presorted = 13; }
-        else if (rlen >= 9) { sort9_optimal(region, is_less); presorted = 9; }
+        if (rlen >= 13) { hit(P_SORT13); sort13_optimal(region, is_less); presorted = 13; }
+        else if (rlen >= 9) { hit(P_SORT9); sort9_optimal(region, is_less); presorted = 9; }
         insertion_sort_shift_left(region, rlen, presorted, is_less);
-        if (no_merge) return;
+        if (no_merge) { hit(P_SMALL_NO_MERGE); return; }
         if (region != v) break;
         region = v + half; rlen = len - half;
     }
     T scratch[32];
+    hit(P_MERGE);
     bidirectional_merge(v, len, scratch, is_less);
     for (size_t i = 0; i < len; ++i) v[i] = scratch[i];
 }
@@ -86,6 +94,7 @@ template <class T, class F> const T* median3_rec(const T* a, const T* b, const T
 template <class T, class F> size_t choose_pivot(const T* v, size_t len, F& is_less) {
     const size_t len_div_8 = len / 8;
     const T *a = v, *b = v + len_div_8 * 4, *c = v + len_div_8 * 7;
+    hit(len < 64 ? P_MEDIAN3 : P_MEDIAN3_REC);
     return (size_t)((len < 64 ? median3(a, b, c, is_less) : median3_rec(a, b, c, len_div_8, is_less)) - v);
 }
 // partition_lomuto_branchless_cyclic over v[0..len) (the slice WITHOUT the pivot)
@@ -121,15 +130,17 @@ template <class T, class F> void heapsort(T* v, size_t len, F& is_less) {
 template <class T, class F> void quicksort(T* v, size_t len, const T* ancestor_pivot, uint32_t limit, F& is_less) {
     for (;;) {
         if (len <= 32) { small_sort_network(v, len, is_less); return; }
-        if (limit == 0) { heapsort(v, len, is_less); return; }
+        if (limit == 0) { hit(P_HEAPSORT); heapsort(v, len, is_less); return; }
         --limit;
         const size_t pivot_pos = choose_pivot(v, len, is_less);
         if (ancestor_pivot && !is_less(*ancestor_pivot, v[pivot_pos])) {
+            hit(P_PARTITION_LE_ANCESTOR);
             auto le = [&](const T& a, const T& b) { return !is_less(b, a); };
             const size_t num_le = partition(v, len, pivot_pos, le);
             v += num_le + 1; len -= num_le + 1; ancestor_pivot = nullptr;
             continue;
         }
+        hit(P_PARTITION_LT);
         const size_t num_lt = partition(v, len, pivot_pos, is_less);
         quicksort(v, num_lt, ancestor_pivot, limit, is_less);
         ancestor_pivot = v + num_lt;
@@ -137,14 +148,16 @@ template <class T, class F> void quicksort(T* v, size_t len, const T* ancestor_p
     }
 }
 template <class T, class F> void sort_unstable_by(T* v, size_t len, F is_less) {
+    hit(P_CALLS);
     if (len < 2) return;
-    if (len <= 20) { insertion_sort_shift_left(v, len, 1, is_less); return; }
+    if (len <= 20) { hit(P_INSERTION_ONLY); insertion_sort_shift_left(v, len, 1, is_less); return; }
     // ipnsort: an existing run over the whole slice?
     size_t run = 2; const bool desc = is_less(v[1], v[0]);
     if (desc) while (run < len && is_less(v[run], v[run - 1])) ++run;
     else      while (run < len && !is_less(v[run], v[run - 1])) ++run;
-    if (run == len) { if (desc) for (size_t i = 0, j = len - 1; i < j; ++i, --j) std::swap(v[i], v[j]); return; }
+    if (run == len) { hit(desc ? P_RUN_DESCENDING : P_RUN_ASCENDING); if (desc) for (size_t i = 0, j = len - 1; i < j; ++i, --j) std::swap(v[i], v[j]); return; }
     uint32_t lg = 0; for (size_t x = len | 1; x > 1; x >>= 1) ++lg;
+    hit(P_QUICKSORT);
     quicksort(v, len, (const T*)nullptr, 2u * lg, is_less);
 }
 }  // namespace rustsort

@@ -128,3 +128,36 @@ def test_parallel_build_is_node_for_node_the_serial_build(native, abi):
         for threads in (2, 3, 8, 16, 0):
             got = build(tris, n, threads)
             assert got[:3] == want[:3], (n, threads)
+
+
+def test_which_sort_branches_the_reference_render_pins(native, oracle_mod, abi):
+    """`sort_unstable_by` is restated, not linked (no Rust toolchain here), and the product's copy is the same text as the oracle's, so
+    the two builders agreeing proves nothing about the sort itself.  What does: the oracle replays the reference's committed render of
+    the text mesh bit for bit (tests/test_oracle_golden.py), and a wrong tie order there moves whole letter faces.  This test records
+    WHICH branches of the algorithm that mesh's 1 675 sorts go through -- those are held by the reference's own picture -- and which
+    are reached only by the teapot meshes or by nothing shipped (held by the restatement alone)."""
+    from oracle import scene_loader
+
+    def paths_of(tri):
+        oracle_mod.sort_paths(reset=True)
+        oracle_mod.bvh_dump(_tri_array(abi, tri))
+        return oracle_mod.sort_paths(reset=True)
+
+    text = paths_of(scene_loader.load_obj(SCENES["semesterbild"].replace("semesterbild.json", "RayTracingText.obj")))
+    assert text["calls"] == 2 * 1675                                    # one sort per inner node of the 3 351-node tree (bvh_dump builds twice: sizes, then data)
+    pinned = {k for k, v in text.items() if v}
+    assert pinned == set(oracle_mod.SORT_PATHS) - {"run_descending", "heapsort"}, sorted(pinned)
+    # (per build: 1 420 slices of <= 20 go to the insertion sort, 138 are already in order, 117 reach the quicksort: both pivot rules,
+    # the <=-partition against an ancestor pivot 37 times, both sorting networks, the bidirectional merge with and without an odd tail)
+    base = SCENES["teapot"].replace("scene.json", "models/")
+    for f in ("Mesh000.wo3", "Mesh001.wo3"):                            # the teapot meshes stay inside what the text mesh pins
+        assert {k for k, v in paths_of(scene_loader.load_wo3(base + f)).items() if v} <= pinned
+    # Not reached by any shipped mesh, i.e. held by the restatement alone: a strictly descending whole slice (reversed in place) and the
+    # heapsort fallback after 2*ilog2(n) unbalanced partitions.  Both at least keep the builders' contract on crafted input:
+    n = 400
+    v = np.zeros((n, 3, 3), np.float32); v[:, :, 0] = (n - np.arange(n, dtype=np.float32))[:, None]; v[:, 1, 1] = 1; v[:, 2, 2] = 1   # centroids strictly descending in x
+    v[:, :, 0] *= 8
+    nrm = np.zeros((n, 3), np.float32); nrm[:, 2] = 1
+    soup = np.concatenate([v.reshape(n, 9), nrm], axis=1)
+    assert paths_of(soup)["run_descending"] > 0
+    _check(abi, native[0], oracle_mod, soup)
