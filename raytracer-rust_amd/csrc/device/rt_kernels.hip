@@ -180,7 +180,8 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 // kernel (rt_wavefront.h, MI355RT_AB_WF_DEFAULTS); the reference build's state-machine / pool kernels keep them (their other lanes'
 // state must not be touched).  WIDE: Philox on 64-bit products (rt_rng.h).  DROP_PRIO: lower the wave's priority to 0 once the
 // fresh samples are dealt (the caller raised it for the memory-bound half of the iteration).  Q0_IN_HIT: see struct Hit.
-template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, class WC>
+// FASTN: see normalized() (rt_math.h).
+template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, bool FASTN = false, class WC>
 DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
@@ -259,14 +260,14 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
                 n_thr = mk(1.f, 1.f, 1.f); n_ri = 0;
                 if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
             } else {
-                scattered = scatter_pre<MATS, WIDE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
+                scattered = scatter_pre<MATS, WIDE, FASTN>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
             }
         }
         prof.mark(5);
         prof.classes(live && !fresh, live && fresh, __float_as_uint(q0.x));
         const f3 ball = unit_ball_cooperative<WIDE>(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
         if (live && !fresh) {
-            if (scattered) scattered = ball_finish(ball_use, h, ball, fuzz, raw);            // (a fuzzed metal reflection may still be absorbed)
+            if (scattered) scattered = ball_finish<FASTN>(ball_use, h, ball, fuzz, raw);     // (a fuzzed metal reflection may still be absorbed)
             if (scattered) {
                 n_thr = ps.thr * atten; n_ro = scatter_origin(h, side); n_ri = ps.ray_index + 1u;
                 if (n_ri == P.max_depth) {                                                   // next level has depth == 0 (renderer.rs:20-22)
@@ -279,7 +280,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
             }
         }
         ps.ro = n_ro; ps.thr = n_thr; ps.ray_index = n_ri;
-        ps.rd = ray_direction(raw);                                                          // fresh and scattered lanes together
+        ps.rd = ray_direction<FASTN>(raw);                                                   // fresh and scattered lanes together
         if (live) ++n_rays;
     }
     prof.mark(3);
@@ -323,6 +324,9 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
 #ifndef MI355RT_GENERAL_CARRY_PO
 #define MI355RT_GENERAL_CARRY_PO true                       // the general mesh-free kernel carries the cube hit point too (see hit_scene): pays at 80 VGPRs
 #endif
+#ifndef MI355RT_AB_FASTN_LS
+#define MI355RT_AB_FASTN_LS true
+#endif
 template <bool HAS_MESH, uint32_t MATS>
 DI void render_ctr_lockstep(const RenderParams& P) {
     constexpr bool SIMPLE = (MATS & ~MATS_LAMBERT) == 0u;
@@ -348,7 +352,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         __builtin_amdgcn_s_setprio(1);
         if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, MI355RT_AB_FASTN_LS>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths

@@ -75,7 +75,7 @@ DI f3 texture_lookup(const DevTexture* __restrict__ texs, uint32_t index, float 
 }
 
 enum : uint32_t { BALL_NONE = 0, BALL_DIFFUSE = 1, BALL_METAL = 2 };    // what a scatter event needs a random_in_unit_sphere point for
-template <uint32_t MATS, bool WIDE = false, class Rng>
+template <uint32_t MATS, bool WIDE = false, bool FASTN = false, class Rng>
 DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, float& side, f3& raw_d, f3& atten, f3& emitted, uint32_t& ball_use, float& fuzz_out) {
     const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
     const uint32_t kind = __float_as_uint(q0.x);
@@ -120,13 +120,13 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
         // addressed draws (try j = block j words 1..3): it is left to the caller's wave-cooperative rejection and ball_finish()
         // adds it.  (As a per-lane loop with a Philox call in it, this branch set the register peak of every general kernel.)
         const float fuzz = m4[1].w;
-        raw_d = mat_reflect(normalized(rd_in), h.n);
+        raw_d = mat_reflect(normalized<FASTN>(rd_in), h.n);
         if (fuzz > 0.0f) { ball_use = BALL_METAL; fuzz_out = fuzz; diffuse = false; }
         else if (!(dot(raw_d, h.n) > 0.0f)) return false;
     } else if (MI_HAS(MI355RT_MAT_DIELECTRIC) && kind == MI355RT_MAT_DIELECTRIC) {                                   // material.rs:122-162
         float ri = m4[1].w;
         float ratio = front_face ? (1.0f / ri) : (ri / 1.0f);
-        f3 unit = normalized(rd_in);
+        f3 unit = normalized<FASTN>(rd_in);
         float cos_theta = fminf(dot(-unit, h.n), 1.0f);
         float sin2 = 1.0f - cos_theta * cos_theta;
         bool cannot_refract = ratio * ratio * sin2 > 1.0f;
@@ -148,7 +148,7 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
         if (has_nan(rd_in)) return false;
         if (has_nan(h.n) || is_zero(h.n)) return false;
         f3 n = h.n;
-        f3 v = -normalized(rd_in);
+        f3 v = -normalized<FASTN>(rd_in);
         if (has_nan(v)) return false;
         const float4 q1 = m4[1], q2 = m4[2], q3 = m4[3];
         float rough = q1.w;
@@ -195,21 +195,24 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
     if (diffuse) ball_use = BALL_DIFFUSE;
     return true;
 }
+template <bool FASTN = false>
 DI f3 diffuse_finish(const Hit& h, f3 p) {                                          // material.rs:54-62
-    f3 dir = h.n + normalized(p);
+    f3 dir = h.n + normalized<FASTN>(p);
     return near_zero(dir) ? h.n : dir;
 }
 // What the accepted unit-ball point turns into: the Lambert-style direction, or the metal's fuzzed reflection, which may be absorbed
 // (material.rs:97-104: `reflected + fuzz * p`, None unless it leaves on the normal's side).  Returns false when absorbed.
+template <bool FASTN = false>
 DI bool ball_finish(uint32_t ball_use, const Hit& h, f3 p, float fuzz, f3& raw) {
-    if (ball_use == BALL_DIFFUSE) raw = diffuse_finish(h, p);
+    if (ball_use == BALL_DIFFUSE) raw = diffuse_finish<FASTN>(h, p);
     else if (ball_use == BALL_METAL) { raw = raw + p * fuzz; return dot(raw, h.n) > 0.0f; }
     return true;
 }
 // What every scatter() and Camera::get_ray end with: `.normalized()` of the direction, then Ray::new normalises again
 // (ray.rs:12-17) -- and the origin offset along the normal.  The callers run it ONCE for all lanes of the wave, whatever
 // branch produced the raw direction (it was the tail of every material branch and of the camera ray: ~66 instructions each).
-DI f3 ray_direction(f3 raw) { return normalized(normalized(raw)); }
+template <bool FASTN = false>
+DI f3 ray_direction(f3 raw) { return normalized<FASTN>(normalized<FASTN>(raw)); }
 DI f3 scatter_origin(const Hit& h, float side) { return h.p + h.n * side; }
 // Sequential composition (reference-stream replay kernel): random_in_unit_sphere as the plain loop, vec3.rs:54-61.
 template <class Rng>

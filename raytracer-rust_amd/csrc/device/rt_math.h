@@ -55,7 +55,26 @@ DI float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          
 DI f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }  // :21-27
 DI float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }                 // :29-31
 DI float len(f3 a) { return sqrtf(len2(a)); }                                     // :33-35
-DI f3 normalized(f3 a) { float l = len(a); if (l < EPS) return a; return a * (1.0f / l); }   // :37-44
+// 1.0f / x for 2^-126 <= |x| < 2^126, +-inf and NaN: v_rcp_f32, one Newton step, v_div_fixup_f32.  Equal to the compiler's correctly
+// rounded division for EVERY such x -- compared exhaustively over all 2^32 bit patterns on the MI355X (tools/microbench/recip.hip,
+// profiles/r03_microbench_reciprocal.txt: the only inputs where the two differ are denormals and |x| >= 2^126, whose reciprocal is a
+// denormal) -- at about half the issue slots (7.5 instead of 14.8).  For callers that can bound their argument.
+DI float recip_normal_range(float x) {
+#ifdef MI355RT_AB_FULL_RECIP
+    return 1.0f / x;
+#else
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return __builtin_amdgcn_div_fixupf(r, x, 1.0f);
+#endif
+}
+// (the length is a square root: at most sqrt(FLT_MAX) = 1.8e19 < 2^126 or +inf / NaN, and at least EPS here)
+// FASTN: with recip_normal_range().  Same bits either way; the kernels of mesh-free lists gain 1.2-1.3 % from it, the wavefront kernels
+// with the BVH walk LOSE 0.4-1.5 % whichever of their normalisations use it (fewer instructions, one more spilled register:
+// profiles/r03_ab_short_reciprocal.txt), so it is a template argument that only the former set.
+template <bool FASTN = false>
+DI f3 normalized(f3 a) { float l = len(a); if (l < EPS) return a; return a * (FASTN ? recip_normal_range(l) : 1.0f / l); }   // :37-44
 DI bool near_zero(f3 a) { const float S = 1e-8f; return fabsf(a.x) < S && fabsf(a.y) < S && fabsf(a.z) < S; }  // :63-66
 DI bool has_nan(f3 a) { return (a.x != a.x) || (a.y != a.y) || (a.z != a.z); }
 DI bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }

@@ -14,6 +14,9 @@
 #ifndef MI355RT_WF_PRIO_WALK
 #define MI355RT_WF_PRIO_WALK 3                              // ... and inside a WALK pass
 #endif
+#ifndef MI355RT_AB_FASTN_WF
+#define MI355RT_AB_FASTN_WF (!HAS_MESH)                     // the short reciprocal in SHADE's normalisations: mesh-free form only (rt_math.h normalized())
+#endif
 #ifndef MI355RT_WF_PRIO_TOP
 #define MI355RT_WF_PRIO_TOP 1                               // ... and over the top-level list (primitive reads); 0 in SHADE's arithmetic
 #endif
@@ -459,7 +462,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             if (any_hit) finish_hit<HAS_MESH, HAS_MESH ? MI355RT_AB_WF_SHARED_TAIL : true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
             // (the priority stays raised through the material read, the radiance store and the work cursor's atomic: shade_and_regenerate
             // drops it to 0 where the arithmetic starts, DROP_PRIO; the list walk below reads primitives again and runs at PRIO_TOP)
-            shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
+            shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true, false, MI355RT_AB_FASTN_WF>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
             if (live) Slot::store_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index);    // a ray to trace: continuing or freshly generated
             const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
             if (lane == 0 && born != died) atomicAdd(&Q.ctrl[16], (uint32_t)(born - died));
