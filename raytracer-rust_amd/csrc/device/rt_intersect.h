@@ -127,11 +127,11 @@ DI uint32_t cube_axis(f3 po) {                                                  
     return (fabsf(ax - 0.5f) < tol) ? 0u : (fabsf(ay - 0.5f) < tol) ? 1u : (fabsf(az - 0.5f) < tol) ? 2u
          : (ax > ay && ax > az) ? 0u : (ay > az) ? 1u : 2u;
 }
-template <class C>
+template <bool FASTR = false, class C>
 DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, C& c) {
     f3 ro = xform_w2o_point(pr, ro_w);
     f3 rd = xform_w2o_dir(pr, rd_w);
-    float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
+    float ix, iy, iz; recip3<FASTR>(rd.x, rd.y, rd.z, ix, iy, iz);                  // (FASTR: the kernels of mesh-free lists, like normalized<FASTN>)
     float t1x = (-0.5f - ro.x) * ix, t2x = (0.5f - ro.x) * ix;
     float t1y = (-0.5f - ro.y) * iy, t2y = (0.5f - ro.y) * iy;
     float t1z = (-0.5f - ro.z) * iz, t2z = (0.5f - ro.z) * iz;
@@ -368,7 +368,7 @@ DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
     while (i < n_prims) {
 #define MI_RUN(KIND, CALL) if (i < n_prims && prims[i].kind == (KIND)) { const uint32_t end = min(prims[i].run_end, n_prims); do { CALL; } while (++i < end); }
         MI_RUN(MI355RT_PRIM_QUAD,   hit_quad(prims + i, i, ro, rd, EPS, c))
-        MI_RUN(MI355RT_PRIM_CUBE,   hit_cube(prims + i, i, ro, rd, EPS, c))
+        MI_RUN(MI355RT_PRIM_CUBE,   hit_cube<!HAS_MESH>(prims + i, i, ro, rd, EPS, c))
         MI_RUN(MI355RT_PRIM_SPHERE, hit_sphere(prims + i, i, ro, rd, EPS, c))
         MI_RUN(MI355RT_PRIM_PLANE,  hit_plane(prims + i, i, ro, rd, EPS, c))
         if (HAS_MESH) { MI_RUN(MI355RT_PRIM_MESH, hit_mesh(prims + i, i, nodes, tris, ro, rd, EPS, c)) }

@@ -73,8 +73,43 @@ DI float recip_normal_range(float x) {
 // FASTN: with recip_normal_range().  Same bits either way; the kernels of mesh-free lists gain 1.2-1.3 % from it, the wavefront kernels
 // with the BVH walk LOSE 0.4-1.5 % whichever of their normalisations use it (fewer instructions, one more spilled register:
 // profiles/r03_ab_short_reciprocal.txt), so it is a template argument that only the former set.
+// 1 / x, 1 / y, 1 / z for ANY arguments: the short form where every lane of the wave has all three in its range (zero counts as
+// in range: v_div_fixup_f32 returns the infinity of the right sign), the compiler's division for the whole wave otherwise -- a
+// wave-uniform branch, so the common case pays three short reciprocals and a range test (two 3-input min / max on the magnitudes).
+// NaN components are ignored by the test and give NaN either way.  (The ballot covers the lanes that are active at the call.)
+template <bool FASTR>
+DI void recip3(float x, float y, float z, float& ix, float& iy, float& iz) {
+#ifndef MI355RT_AB_FULL_RECIP3
+    if constexpr (FASTR) {
+    const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+    const float mx = fmaxf(fmaxf(ax, ay), az);
+    const float mn = fminf(fminf(ax == 0.0f ? 1.0f : ax, ay == 0.0f ? 1.0f : ay), az == 0.0f ? 1.0f : az);
+    if (__ballot((mn < 0x1p-126f) || (mx >= 0x1p126f)) == 0ull) { ix = recip_normal_range(x); iy = recip_normal_range(y); iz = recip_normal_range(z); return; }
+    }
+#endif
+    ix = 1.0f / x; iy = 1.0f / y; iz = 1.0f / z;
+}
+
+// The length normalized() needs: bit-equal to sqrtf(x) for every x >= 2^-100, +inf and NaN; for 0 <= x < 2^-100 (a length below
+// 1e-15) it returns 0, which normalized() treats like the true value -- both are below its 1e-4 pass-through threshold.  v_rsq_f32 +
+// one residual correction instead of the compiler's expansion (denormal scaling, v_sqrt_f32, both neighbours tested): 9 instead of 17
+// issue slots.  The contract was checked for EVERY x >= +0 and every NaN on the MI355X (tools/microbench/sqrt.hip, k_contract:
+// 0 violations; profiles/r03_microbench_sqrt.txt).  x is a sum of squares here: never negative, never -0.
+DI float length_for_normalize(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, x);
+    float s = __builtin_fmaf(d, h, g);
+    s = (x < 0x1p-100f) ? 0.0f : s;
+    return (x == __builtin_inff()) ? x : s;
+}
 template <bool FASTN = false>
-DI f3 normalized(f3 a) { float l = len(a); if (l < EPS) return a; return a * (FASTN ? recip_normal_range(l) : 1.0f / l); }   // :37-44
+DI f3 normalized(f3 a) {                                                          // :37-44
+#ifndef MI355RT_AB_FULL_SQRT
+    if constexpr (FASTN) { const float l = length_for_normalize(len2(a)); if (l < EPS) return a; return a * recip_normal_range(l); }
+#endif
+    const float l = len(a); if (l < EPS) return a; return a * (FASTN ? recip_normal_range(l) : 1.0f / l);
+}
 DI bool near_zero(f3 a) { const float S = 1e-8f; return fabsf(a.x) < S && fabsf(a.y) < S && fabsf(a.z) < S; }  // :63-66
 DI bool has_nan(f3 a) { return (a.x != a.x) || (a.y != a.y) || (a.z != a.z); }
 DI bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }

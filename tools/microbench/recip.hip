@@ -48,7 +48,14 @@ template <int V> void timeit(const char* name, float* d) {
     hipEventRecord(e0); hipLaunchKernelGGL(k_time<V>, dim3(256 * 7), dim3(256), 0, 0, d, 20000); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); printf("%-40s %8.3f ms\n", name, ms);
 }
+__global__ void k_zeros(uint32_t* out) {
+    const uint32_t pat[6] = {0x00000000u, 0x80000000u, 0x00000001u, 0x80000001u, 0x00200000u, 0x80200000u};
+    for (int i = 0; i < 6; ++i) { const float x = __uint_as_float(pat[i]); out[2 * i] = __float_as_uint(recip_full(x)); out[2 * i + 1] = __float_as_uint(recip_short<1>(x)); }
+}
 int main() {
+    { uint32_t* o; hipMalloc(&o, 48); hipLaunchKernelGGL(k_zeros, dim3(1), dim3(1), 0, 0, o); uint32_t h[12]; hipMemcpy(h, o, 48, hipMemcpyDeviceToHost);
+      const char* n[6] = {"+0", "-0", "+min denormal", "-min denormal", "+2^-128", "-2^-128"};
+      for (int i = 0; i < 6; ++i) printf("1/%-14s compiler 0x%08x  short 0x%08x  %s\n", n[i], h[2 * i], h[2 * i + 1], h[2 * i] == h[2 * i + 1] ? "equal" : "DIFFERENT"); }
     check<0>("v_rcp + fixup"); check<1>("v_rcp + 1 Newton step + fixup"); check<2>("v_rcp + 2 Newton steps + fixup");
     float* d; hipMalloc(&d, 256 * 7 * 256 * 4);
     timeit<-1>("1.0f / x (compiler, correctly rounded)", d); timeit<0>("v_rcp + fixup", d); timeit<1>("v_rcp + 1 Newton step + fixup", d); timeit<2>("v_rcp + 2 Newton steps + fixup", d);
