@@ -189,13 +189,21 @@ struct MeshTrav {
     float best_t; uint32_t best_tri;
     uint32_t leaf_a, leaf_b;   // pending leaf (first triangle, count); leaf_b == 0: none
 };
-template <class PrimPtr>
+// FAST: the short reciprocal / square root of rt_math.h (same bits; a template argument because the kernels' register allocation
+// decides whether the shorter code is also the faster one).
+template <bool FAST = false, class PrimPtr>
 DI void mesh_setup(PrimPtr pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {   // mesh_object.rs:264-291
     m.ro = xform_w2o_point(pr, ro_w);
     f3 rd_raw = xform_w2o_dir(pr, rd_w);
     m.len_raw = len(rd_raw);
+    if constexpr (FAST) {
+        const f3 once = (m.len_raw < EPS) ? rd_raw : rd_raw * recip_normal_range(m.len_raw);     // normalized(): the length is the one above
+        m.rd = normalized<true>(once);
+        recip3<true>(m.rd.x, m.rd.y, m.rd.z, m.ix, m.iy, m.iz);
+    } else {
     m.rd = normalized(normalized(rd_raw));
     m.ix = 1.0f / m.rd.x; m.iy = 1.0f / m.rd.y; m.iz = 1.0f / m.rd.z;
+    }
     m.node = pr->node_begin;
     m.best_t = t_max; m.best_tri = 0xFFFFFFFFu; m.leaf_b = 0; m.leaf_a = 0;
 }
@@ -263,7 +271,7 @@ DI void mesh_leaf(const float4* __restrict__ t4, float t_min, MeshTrav& m) {
         const f3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
         f3 hh = cross(m.rd, e2);
         float aa = dot(e1, hh);
-        float f = 1.0f / aa;
+        float f = 1.0f / aa;                                 // (the short reciprocal of rt_math.h, guarded by a ballot on |aa| >= 2^126, measured +-0.1 %: not taken)
         f3 s = m.ro - v0;
         float u = f * dot(s, hh);
         f3 q = cross(s, e1);

@@ -14,6 +14,15 @@
 #ifndef MI355RT_WF_PRIO_WALK
 #define MI355RT_WF_PRIO_WALK 3                              // ... and inside a WALK pass
 #endif
+// The short reciprocal / square root (rt_math.h) in mesh_setup, where TOP meets a mesh and where a WALK pass re-enters one, and in TOP's
+// cube test: semesterbild 27.13 -> 26.77 ms, teapot 16.31 -> 16.09 (profiles/r03_ab_short_reciprocal.txt); in SHADE's normalisations
+// as well (MI355RT_AB_FASTN_WF) the same kernels lose a third of that again, so there only the mesh-free form uses them.
+#ifndef MI355RT_AB_FAST_MESH_TOP
+#define MI355RT_AB_FAST_MESH_TOP true
+#endif
+#ifndef MI355RT_AB_FAST_MESH_WALK
+#define MI355RT_AB_FAST_MESH_WALK true
+#endif
 #ifndef MI355RT_AB_FASTN_WF
 #define MI355RT_AB_FASTN_WF (!HAS_MESH)                     // the short reciprocal in SHADE's normalisations: mesh-free form only (rt_math.h normalized())
 #endif
@@ -317,11 +326,11 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                     case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ro, rd, EPS, c); break;
                     case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ro, rd, EPS, c); break;
                     case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ro, rd, EPS, c); break;
-                    case MI355RT_PRIM_CUBE:   hit_cube<!HAS_MESH>(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_CUBE:   hit_cube<!HAS_MESH || MI355RT_AB_FAST_MESH_TOP>(pr, i, ro, rd, EPS, c); break;
                     default:
                         if constexpr (!HAS_MESH) break;                // (the host picks this instantiation for mesh-free lists only)
                         else if (!walk_done) {
-                            MeshTrav mt; mesh_setup(pr, ro, rd, c.t, mt);
+                            MeshTrav mt; mesh_setup<MI355RT_AB_FAST_MESH_TOP>(pr, ro, rd, c.t, mt);
                             const uint32_t root = mt.node;
                             mesh_step<FIXED_AABB, WF_LDS_MODE>(n4, lds, lds_count, EPS, mt);       // the root box, here: most rays miss it
                             if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
@@ -495,7 +504,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 f3 ro_w, rd_w; uint32_t cur; WalkRec w;
                 Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
                 const DevPrim* __restrict__ pr = P.prims + cur;                                          // lanes may be in different meshes
-                mesh_setup(pr, ro_w, rd_w, 0.f, m);                                                      // the object-space ray, as TOP computed it
+                mesh_setup<MI355RT_AB_FAST_MESH_WALK>(pr, ro_w, rd_w, 0.f, m);                                                      // the object-space ray, as TOP computed it
                 m.node = w.node; m.best_t = w.best_t; m.best_tri = w.best_tri;
             }
 #if MI355RT_WF_SPEC
