@@ -70,9 +70,9 @@ DI float recip_normal_range(float x) {
 #endif
 }
 // (the length is a square root: at most sqrt(FLT_MAX) = 1.8e19 < 2^126 or +inf / NaN, and at least EPS here)
-// FASTN: with recip_normal_range().  Same bits either way; the kernels of mesh-free lists gain 1.2-1.3 % from it, the wavefront kernels
-// with the BVH walk LOSE 0.4-1.5 % whichever of their normalisations use it (fewer instructions, one more spilled register:
-// profiles/r03_ab_short_reciprocal.txt), so it is a template argument that only the former set.
+// FASTN: with length_for_normalize() and recip_normal_range().  Same bits either way; the kernels of mesh-free lists gain 2-3 % from it
+// in their shading step, the wavefront kernels with the BVH walk LOSE 0.4-1.5 % there (fewer instructions, one more spilled
+// register) and gain only in mesh_setup (profiles/r03_ab_short_reciprocal.txt) -- so it is a template argument set site by site.
 // 1 / x, 1 / y, 1 / z for ANY arguments: the short form where every lane of the wave has all three in its range (zero counts as
 // in range: v_div_fixup_f32 returns the infinity of the right sign), the compiler's division for the whole wave otherwise -- a
 // wave-uniform branch, so the common case pays three short reciprocals and a range test (two 3-input min / max on the magnitudes).
