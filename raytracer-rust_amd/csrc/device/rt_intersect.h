@@ -79,10 +79,19 @@ DI bool hit_plane(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
 // tungsten/objects/quad.rs:83-132.  The two cheap rejections (parallel ray, t out of range) are folded into one
 // predicate so the wave takes a single branch into the parallelogram test; the arithmetic is unchanged (the
 // division also runs for |denom| < EPS lanes, whose result is discarded).
+// FASTD: t by div_bounded() (rt_math.h).  t is used only where |denom| >= EPS, and |denom| <= |n||d| ~ 1, so the divisor is in range; a
+// numerator below 2^-100 gives a |t| below 2^-86 either way (rejected: t <= t_min), one of 2^100 or more sends the whole wave to the
+// compiler's division (ballot); infinities and NaN come out of v_div_fixup_f32 as they do there.
+template <bool FASTD = false>
 DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     f3 n = mk(pr->d[9], pr->d[10], pr->d[11]);
     float denom = dot(n, rd);
-    float t = (pr->d[12] - dot(n, ro)) / denom;
+    const float num = pr->d[12] - dot(n, ro);
+    float t;
+#ifndef MI355RT_AB_FULL_DIV
+    if (FASTD && __ballot(fabsf(num) >= 0x1p100f) == 0ull) t = div_bounded(num, denom); else
+#endif
+    t = num / denom;
     const bool candidate = !(fabsf(denom) < EPS) && !(t <= t_min || t >= c.t);
     // branch-free in the source: cornell 19.74 -> 19.61 ms, veach-mis +-0 with the 4-register candidate (the compiler still branches
     // around the parallelogram test where a whole wave can skip it)
@@ -375,7 +384,7 @@ DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
     uint32_t i = 0;
     while (i < n_prims) {
 #define MI_RUN(KIND, CALL) if (i < n_prims && prims[i].kind == (KIND)) { const uint32_t end = min(prims[i].run_end, n_prims); do { CALL; } while (++i < end); }
-        MI_RUN(MI355RT_PRIM_QUAD,   hit_quad(prims + i, i, ro, rd, EPS, c))
+        MI_RUN(MI355RT_PRIM_QUAD,   hit_quad<!HAS_MESH>(prims + i, i, ro, rd, EPS, c))
         MI_RUN(MI355RT_PRIM_CUBE,   hit_cube<!HAS_MESH>(prims + i, i, ro, rd, EPS, c))
         MI_RUN(MI355RT_PRIM_SPHERE, hit_sphere(prims + i, i, ro, rd, EPS, c))
         MI_RUN(MI355RT_PRIM_PLANE,  hit_plane(prims + i, i, ro, rd, EPS, c))

@@ -253,8 +253,10 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
         ps.rng.template load_block0<WIDE>();
         if (live) {
             if (fresh) {
-                const float u = ((float)ps.px + ps.rng.jitter_u()) / (float)P.width;         // renderer.rs:96
-                const float v = ((float)ps.py + ps.rng.jitter_v()) / (float)P.height;        // renderer.rs:97
+                // (FASTN: div_bounded -- the dividend is 0 or in [2^-24, 2^24), the divisor an image dimension in [1, 2^24))
+                const float un = (float)ps.px + ps.rng.jitter_u(), vn = (float)ps.py + ps.rng.jitter_v();
+                const float u = FASTN ? div_bounded(un, (float)P.width) : un / (float)P.width;     // renderer.rs:96
+                const float v = FASTN ? div_bounded(vn, (float)P.height) : vn / (float)P.height;   // renderer.rs:97
                 raw = camera_raw(P.cam, u, v);                                               // renderer.rs:99; normalised below with the scattered rays
                 n_ro = mk(P.cam.position[0], P.cam.position[1], P.cam.position[2]);
                 n_thr = mk(1.f, 1.f, 1.f); n_ri = 0;

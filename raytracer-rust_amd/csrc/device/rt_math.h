@@ -73,6 +73,19 @@ DI float recip_normal_range(float x) {
 // FASTN: with length_for_normalize() and recip_normal_range().  Same bits either way; the kernels of mesh-free lists gain 2-3 % from it
 // in their shading step, the wavefront kernels with the BVH walk LOSE 0.4-1.5 % there (fewer instructions, one more spilled
 // register) and gain only in mesh_setup (profiles/r03_ab_short_reciprocal.txt) -- so it is a template argument set site by site.
+// a / b by the exact reciprocal and ONE correction: r = RN(1/b) (above), q0 = a*r, e = fma(-b, q0, a), q = fma(e, r, q0), v_div_fixup_f32 for
+// infinities / NaN / zeros.  Equal to the compiler's correctly rounded division for all 2^23 x 2^23 pairs of significands (enumerated on the
+// MI355X in 43 s: tools/microbench/div.hip, profiles/r03_microbench_division.txt); rounding commutes with scaling by powers of two while
+// everything stays normal, so it IS a / b whenever 2^-25 <= |b| <= 2^25 and (a == 0 or 2^-100 <= |a| <= 2^100) -- 11 + 1.5 issue slots
+// instead of 18.5.  For callers that can bound their arguments (or guard them with a ballot) and do not use the result elsewhere.
+DI float div_bounded(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    { const float e = __builtin_fmaf(-b, r, 1.0f); r = __builtin_fmaf(e, r, r); }
+    float q = a * r;
+    { const float e = __builtin_fmaf(-b, q, a); q = __builtin_fmaf(e, r, q); }
+    return __builtin_amdgcn_div_fixupf(q, b, a);
+}
+
 // 1 / x, 1 / y, 1 / z for ANY arguments: the short form where every lane of the wave has all three in its range (zero counts as
 // in range: v_div_fixup_f32 returns the infinity of the right sign), the compiler's division for the whole wave otherwise -- a
 // wave-uniform branch, so the common case pays three short reciprocals and a range test (two 3-input min / max on the magnitudes).

@@ -325,7 +325,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 switch (pr->kind) {                                       // wave-uniform: scalar branch
                     case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ro, rd, EPS, c); break;
                     case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ro, rd, EPS, c); break;
-                    case MI355RT_PRIM_QUAD:   hit_quad(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_QUAD:   hit_quad<!HAS_MESH || MI355RT_AB_FAST_MESH_TOP>(pr, i, ro, rd, EPS, c); break;
                     case MI355RT_PRIM_CUBE:   hit_cube<!HAS_MESH || MI355RT_AB_FAST_MESH_TOP>(pr, i, ro, rd, EPS, c); break;
                     default:
                         if constexpr (!HAS_MESH) break;                // (the host picks this instantiation for mesh-free lists only)

@@ -46,6 +46,16 @@ def test_float_conversions(oracle_mod):
     assert -1.0 <= L.oracle_u32_to_range11(0) and L.oracle_u32_to_range11(0xFFFFFFFF) < 1.0
 
 
+def test_range11_short_form_equals_rands_formula_for_every_mantissa():
+    """The device computes random_range(-1.0..1.0) as (the float in [2, 4) with mantissa k) - 3 (csrc/device/rt_rng.h u32_to_range11);
+    the oracle and the rand crate compute (value1_2 - 1.0) * 2.0 + -1.0.  All 2^23 values of k = w >> 9, in IEEE f32: same bits."""
+    k = np.arange(1 << 23, dtype=np.uint32)
+    v12 = (k | np.uint32(0x3F800000)).view(np.float32)
+    rand_form = ((v12 - np.float32(1.0)) * np.float32(2.0) + np.float32(-1.0)).astype(np.float32)
+    short_form = ((k | np.uint32(0x40000000)).view(np.float32) - np.float32(3.0)).astype(np.float32)
+    assert np.array_equal(rand_form.view(np.uint32), short_form.view(np.uint32))
+
+
 def test_philox4x32_10_kat(oracle_mod):
     assert oracle_mod.philox(0, 0, 0, 0, 0, 0).tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
     f = 0xFFFFFFFF
