@@ -120,6 +120,20 @@ def build_cli(force=False, verbose=False):
     return CLI
 
 
+def build_verify(force=False, verbose=False):
+    """tools/verify/short_arithmetic: the exhaustive comparison of rt_math.h's short reciprocal / square root / division (and rt_rng.h's
+    range conversion) with the compiler's correctly rounded forms -- the product's headers, the product's flags, a standalone program
+    that a gpu test runs (tests/test_gpu_short_arithmetic.py)."""
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify", "short_arithmetic.hip")
+    exe = src[:-4]
+    if force or _stale(exe, [src] + DEVICE_HEADERS):
+        cmd = [hipcc_path(), *[f for f in HIPCC_FLAGS if f not in ("-fPIC", "-shared")], "-o", exe, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return exe
+
+
 def build_all(force=False, verbose=False):
     return build_device(force, verbose=verbose), build_host(force, verbose=verbose), build_cli(force, verbose=verbose)
 
