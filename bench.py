@@ -303,7 +303,9 @@ def main():
                                                  "bytes_per_step": int(bytes_per_sample * local_samples),
                                                  "note": "SURVEY.md 8d algorithmic bytes; SGPR/L2 resident, never reach HBM -- a model, not an HBM fraction"},
                          "note": "achieved = SQ_INSTS_VALU per step (PMC, profiles/pmc_counters.json, same kernel hash) / live HIP-event kernel time per step; "
-                                 "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction"
+                                 "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (nominal: a loop of nothing but independent "
+                                 "v_mul_f32 / v_add_f32 reaches 0.82-0.94 of it at a sustained 2.32-2.39 GHz -- tools/microbench/clock.hip, "
+                                 "profiles/r03_microbench_clock_and_issue.txt -- and v_fma / v_rcp / v_sqrt / 64-bit multiplies take more than one slot)"
                                  + ("; frames overlap on two streams here, so the kernel's event time includes time it shared the chip" if depth_pipe > 1 else "")},
             "cpu_baseline": cpu_baseline,
             **({"tail": tail} if tail else {}),
