@@ -127,7 +127,7 @@ def build_verify(force=False, verbose=False):
     src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify", "short_arithmetic.hip")
     exe = src[:-4]
     if force or _stale(exe, [src] + DEVICE_HEADERS):
-        cmd = [hipcc_path(), *[f for f in HIPCC_FLAGS if f not in ("-fPIC", "-shared")], "-o", exe, src]
+        cmd = [hipcc_path(), *[f for f in HIPCC_FLAGS if f not in ("-fPIC", "-shared")], "-Wno-unused-value", "-Wno-unused-result", "-o", exe, src]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
