@@ -134,11 +134,16 @@ struct PathState {
 // Must be called in wave-uniform control flow.
 DI int lane_shfl(int v, uint32_t src_lane) { return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), v); }
 DI float lane_shfl(float v, uint32_t src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v))); }
-template <bool WIDE = false>
-DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
+template <bool WIDE = false, bool TRY1 = false>
+DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane, const uint32_t* b1 = nullptr) {
     f3 p = mk(u32_to_range11(rng.b0[1]), u32_to_range11(rng.b0[2]), u32_to_range11(rng.b0[3]));   // try 0
     bool need = diffuse && !(len2(p) < 1.0f);
     uint32_t jbase = 1;
+    if constexpr (TRY1) {                                                          // try 1 was drawn in the lane itself, next to the event's block
+        const f3 p1 = mk(u32_to_range11(b1[1]), u32_to_range11(b1[2]), u32_to_range11(b1[3]));
+        if (need && len2(p1) < 1.0f) { p = p1; need = false; }
+        jbase = 2;                                                                 // (tries 1 AND 2 in the lane: the same kernel spills, 14.8 -> 17.9 ms)
+    }
     for (;;) {
         const uint64_t m = __ballot(need);
         if (m == 0ull) break;
@@ -180,8 +185,10 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane) {
 // kernel (rt_wavefront.h, MI355RT_AB_WF_DEFAULTS); the reference build's state-machine / pool kernels keep them (their other lanes'
 // state must not be touched).  WIDE: Philox on 64-bit products (rt_rng.h).  DROP_PRIO: lower the wave's priority to 0 once the
 // fresh samples are dealt (the caller raised it for the memory-bound half of the iteration).  Q0_IN_HIT: see struct Hit.
-// FASTN: see normalized() (rt_math.h).
-template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, bool FASTN = false, class WC>
+// FASTN: see normalized() (rt_math.h).  TRY1: try 1 of the unit-ball draw comes from a second Philox block drawn in the lane itself, right after the
+// event's block, so the cooperative rounds start at try 2 and a second round is needed in 44 % of the iterations instead of all: cornell -0.9 %
+// on the Lambert-only kernel; every other kernel pays for the three more live registers with spills (+1.5 ... +23 %: profiles/r03_ab_inlane_try1.txt).
+template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, bool FASTN = false, bool TRY1 = false, class WC>
 DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
@@ -251,6 +258,8 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
         f3 n_ro, n_thr; uint32_t n_ri;
         if (!fresh) ps.rng.next_event();
         ps.rng.template load_block0<WIDE>();
+        uint32_t blk1[4] = {0u, 0u, 0u, 0u};
+        if constexpr (TRY1) philox4x32_10<WIDE>(ps.rng.k0, ps.rng.k1, ps.rng.x, ps.rng.s, ps.rng.ray, 1u, blk1);
         if (live) {
             if (fresh) {
                 // (FASTN: div_bounded -- the dividend is 0 or in [2^-24, 2^24), the divisor an image dimension in [1, 2^24))
@@ -267,7 +276,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
         }
         prof.mark(5);
         prof.classes(live && !fresh, live && fresh, __float_as_uint(q0.x));
-        const f3 ball = unit_ball_cooperative<WIDE>(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
+        const f3 ball = unit_ball_cooperative<WIDE, TRY1>(scattered && ball_use != BALL_NONE, ps.rng, lane, blk1);   // whole wave, uniform control flow
         if (live && !fresh) {
             if (scattered) scattered = ball_finish<FASTN>(ball_use, h, ball, fuzz, raw);     // (a fuzzed metal reflection may still be absorbed)
             if (scattered) {
@@ -329,6 +338,9 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
 #ifndef MI355RT_AB_FASTN_LS
 #define MI355RT_AB_FASTN_LS true
 #endif
+#ifndef MI355RT_AB_TRY1_SIMPLE
+#define MI355RT_AB_TRY1_SIMPLE true
+#endif
 template <bool HAS_MESH, uint32_t MATS>
 DI void render_ctr_lockstep(const RenderParams& P) {
     constexpr bool SIMPLE = (MATS & ~MATS_LAMBERT) == 0u;
@@ -354,7 +366,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         __builtin_amdgcn_s_setprio(1);
         if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, MI355RT_AB_FASTN_LS>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, MI355RT_AB_FASTN_LS, SIMPLE && MI355RT_AB_TRY1_SIMPLE>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths
