@@ -660,6 +660,8 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         p.n_prims = ctx->n_prims; p.n_mats = ctx->n_mats;
         std::memcpy(p.miss, ctx->miss, 12); p.cam = ctx->cam;
         p.width = st.width; p.height = st.height; p.spp = (uint32_t)spp; p.max_depth = st.max_depth;
+        p.width_f = (float)st.width; p.height_f = (float)st.height;                       // exact: both below 2^24
+        { volatile float one = 1.0f; p.inv_width_rn = one / p.width_f; p.inv_height_rn = one / p.height_f; }   // IEEE division on the host = RN(1/x), what recip_normal_range() returns on the device
         p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.sample0 = s0;
         magic_div((uint32_t)spp, p.spp_mul, p.spp_shift); magic_div(st.width, p.width_mul, p.width_shift);
         p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;

@@ -103,6 +103,8 @@ struct RenderParams {
     float miss[3];
     DevCamera cam;
     uint32_t width, height, spp, max_depth;
+    float width_f, height_f, inv_width_rn, inv_height_rn;   // (float)width, (float)height and their correctly rounded reciprocals (host: 1.0f / x): the
+                                                            // camera's u = x / width by div_by_rn() with every divisor-side operand in scalar registers
     uint32_t band_pixel0;        // first local pixel (row-major over the selected rows) of this band
     uint32_t band_samples;       // band pixels * spp  (< 2^31)
     uint32_t guided_div;         // run length = (left in the shard) / guided_div, clamped to the kernel's [RMIN, RMAX] (WorkCursorT)

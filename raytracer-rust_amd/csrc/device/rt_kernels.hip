@@ -262,10 +262,11 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
         if constexpr (TRY1) philox4x32_10<WIDE>(ps.rng.k0, ps.rng.k1, ps.rng.x, ps.rng.s, ps.rng.ray, 1u, blk1);
         if (live) {
             if (fresh) {
-                // (FASTN: div_bounded -- the dividend is 0 or in [2^-24, 2^24), the divisor an image dimension in [1, 2^24))
+                // (FASTN: div_bounded with the host's RN(1/width) -- the dividend is 0 or in [2^-24, 2^24), the divisor an image dimension in [1, 2^24);
+                //  with the reciprocal computed in the kernel the compiler hoisted it into four vector registers that the loop then spilled)
                 const float un = (float)ps.px + ps.rng.jitter_u(), vn = (float)ps.py + ps.rng.jitter_v();
-                const float u = FASTN ? div_bounded(un, (float)P.width) : un / (float)P.width;     // renderer.rs:96
-                const float v = FASTN ? div_bounded(vn, (float)P.height) : vn / (float)P.height;   // renderer.rs:97
+                const float u = FASTN ? div_by_rn(un, P.width_f, P.inv_width_rn) : un / (float)P.width;       // renderer.rs:96
+                const float v = FASTN ? div_by_rn(vn, P.height_f, P.inv_height_rn) : vn / (float)P.height;    // renderer.rs:97
                 raw = camera_raw(P.cam, u, v);                                               // renderer.rs:99; normalised below with the scattered rays
                 n_ro = mk(P.cam.position[0], P.cam.position[1], P.cam.position[2]);
                 n_thr = mk(1.f, 1.f, 1.f); n_ri = 0;

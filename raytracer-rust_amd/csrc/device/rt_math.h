@@ -86,6 +86,14 @@ DI float div_bounded(float a, float b) {
     return __builtin_amdgcn_div_fixupf(q, b, a);
 }
 
+// div_bounded() with the reciprocal handed in (r must be RN(1/b), e.g. the host's 1.0f / b): for a divisor that is the same for the whole
+// launch the reciprocal and its Newton step are not even hoisted into vector registers -- b and r stay scalar operands.
+DI float div_by_rn(float a, float b, float r) {
+    float q = a * r;
+    { const float e = __builtin_fmaf(-b, q, a); q = __builtin_fmaf(e, r, q); }
+    return __builtin_amdgcn_div_fixupf(q, b, a);
+}
+
 // 1 / x, 1 / y, 1 / z for ANY arguments: the short form where every lane of the wave has all three in its range (zero counts as
 // in range: v_div_fixup_f32 returns the infinity of the right sign), the compiler's division for the whole wave otherwise -- a
 // wave-uniform branch, so the common case pays three short reciprocals and a range test (two 3-input min / max on the magnitudes).
