@@ -3,7 +3,7 @@
 //   recip_normal_range(x) == 1.0f / x      for all 2^32 x except denormals and |x| >= 2^126 (and is checked to differ ONLY there)
 //   recip3<true>(x, 1.5, -3)               == 1.0f / x for ALL 2^32 x (its ballot sends the others to the compiler's division)
 //   length_for_normalize(x)                == sqrtf(x) for x >= 2^-100, +inf, NaN; below 1e-4 (and not NaN) for 0 <= x < 2^-100
-//   div_bounded(a, b)                      == a / b for the pairs of significands enumerated (argv[1] chunks of 2^17 b x all 2^23 a; 64 = all 2^46)
+//   div_bounded(a, b), div_by_rn(a, b, 1/b) == a / b for the pairs of significands enumerated (argv[1] chunks of 2^17 b x all 2^23 a; 64 = all 2^46)
 //   u32_to_range11(w)                      == (value1_2 - 1) * 2 - 1 for all 2^23 mantissas
 // usage: short_arithmetic [division chunks, default 2]     exit code 0 = every check passed
 #include <hip/hip_runtime.h>
@@ -36,13 +36,15 @@ __global__ void k_sqrt(unsigned long long* out) {
 __global__ void __launch_bounds__(256) k_div(unsigned long long* out, uint32_t b_base) {
     const float b = __uint_as_float(0x3F800000u | (b_base + blockIdx.x * blockDim.x + threadIdx.x));
     unsigned long long bad = 0;
-    for (uint32_t am = 0; am < (1u << 23); ++am) { const float a = __uint_as_float(0x3F800000u | am); bad += __float_as_uint(a / b) != __float_as_uint(div_bounded(a, b)); }
+    const float rb = 1.0f / b;                                           // what the host hands div_by_rn(): the correctly rounded reciprocal
+    for (uint32_t am = 0; am < (1u << 23); ++am) { const float a = __uint_as_float(0x3F800000u | am); const uint32_t want = __float_as_uint(a / b);
+                                                   bad += (want != __float_as_uint(div_bounded(a, b))) + (want != __float_as_uint(div_by_rn(a, b, rb))); }
     if (bad) atomicAdd(&out[0], bad);
 }
 __global__ void k_div_specials(unsigned long long* out) {   // zeros, infinities, NaN, the ends of the stated range, negative operands
     const float as[] = {0.0f, -0.0f, 0x1p-100f, -0x1p-100f, 0x1.fffffep99f, 1.0f, -3.0f, 0x1p-24f, 16777215.0f, __builtin_inff(), -__builtin_inff(), __builtin_nanf("")};
     const float bs[] = {0x1p-25f, -0x1p-25f, 0x1.fffffep24f, 1.0f, -1.0f, 3.0f, 800.0f, 600.0f, 1e-4f, 0.7071068f, __builtin_inff(), __builtin_nanf("")};
-    for (float a : as) for (float b : bs) if (!same(a / b, div_bounded(a, b))) atomicAdd(&out[0], 1ull);
+    for (float a : as) for (float b : bs) if (!same(a / b, div_bounded(a, b)) || !same(a / b, div_by_rn(a, b, 1.0f / b))) atomicAdd(&out[0], 1ull);
 }
 __global__ void k_range11(unsigned long long* out) {
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < (1u << 23); k += gridDim.x * blockDim.x) {
@@ -63,7 +65,7 @@ int main(int argc, char** argv) {
     printf("length_for_normalize: %llu contract violations over every x >= +0 and every NaN (want 0)\n", h[0]); fails += h[0] != 0;
     for (int c = 0; c < chunks && c < 64; ++c) hipLaunchKernelGGL(k_div, dim3(512), dim3(256), 0, 0, d, (uint32_t)(c * (64 / (chunks < 64 ? chunks : 64))) << 17);
     fetch();
-    printf("div_bounded: %llu differences over %d x 2^17 b significands x all 2^23 a significands (want 0)\n", h[0], chunks); fails += h[0] != 0;
+    printf("div_bounded, div_by_rn: %llu differences over %d x 2^17 b significands x all 2^23 a significands (want 0)\n", h[0], chunks); fails += h[0] != 0;
     hipLaunchKernelGGL(k_div_specials, dim3(1), dim3(1), 0, 0, d); fetch();
     printf("div_bounded: %llu differences on zeros / infinities / NaN / range ends (want 0)\n", h[0]); fails += h[0] != 0;
     hipLaunchKernelGGL(k_range11, dim3(512), dim3(256), 0, 0, d); fetch();
