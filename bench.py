@@ -2,7 +2,13 @@
 """bench.py -- headline benchmark of the MI355X render loop (contract in the task statement / DESIGN.md section 6).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1, two ways in:
+   * under a launcher (RANK / WORLD_SIZE in the environment): python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+     -- this process is one rank;
+   * as typed, `python bench.py --gpus N`: this process never touches the GPU; it starts that launcher itself as a fresh child process
+     (127.0.0.1, a free port), relays its output and exits with its code.  If the ranks cannot be started or end without a result line, it
+     starts a second fresh child in --single-process mode: ONE process drives all N devices (a context + stream per device, the same strip plan,
+     the gather by device-to-device copies into device 0).  The JSON line says which way ran ("launch").
 
 A "step" is ONE full render of the workload -- by default BASELINE.json configs[1]: cornell-box scene.json at
 800x600, 256 spp, max_bounces 30 -- through the C ABI with the scene already resident in HBM: path-tracing
@@ -112,7 +118,7 @@ def load_pmc(workload, kernel_hash, kernel_name=None):
     return rec, "fresh"
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -126,7 +132,17 @@ def main():
                     help="after the timed region also time 1/P-image launches (strip part p of P, every p) on this GPU: "
                          "what one of P GPUs would run; reports ideal (full/P) vs measured")
     ap.add_argument("--save-png", default="")
-    args = ap.parse_args()
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 without a launcher: one process, one context + stream per device, gather by device-to-device copies into device 0 "
+                         "(what `bench.py --gpus N` falls back to when the one-rank-per-GPU launch cannot start)")
+    args = ap.parse_args(argv)
+
+    # `python bench.py --gpus N` as typed (no launcher around it): start the ranks ourselves, in fresh child processes, BEFORE anything here
+    # imports torch or touches the GPU.  (MI355RT_BENCH_FORCE_DIST=1 takes the same route with N = 1: the RCCL branch with one rank.)
+    if "RANK" not in os.environ and not args.single_process and (args.gpus > 1 or os.environ.get("MI355RT_BENCH_FORCE_DIST") == "1"):
+        sys.exit(self_launch(args, list(sys.argv[1:] if argv is None else argv)))
+    if args.single_process:
+        return main_single_process(args)
 
     # RCCL sets up its intra-node transport with HIP IPC handles; on this pool the host driver only supports dmabuf IPC, and the
     # legacy mode fails in `hipIpcGetMemHandle: invalid argument` as soon as there are two ranks.  The variable has to be in the
@@ -136,18 +152,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:                                   # under a launcher the launcher's world size is the truth
         args.gpus = world
 
     import torch
     import torch.distributed as dist
-    abi = importlib.import_module("raytracer-rust_amd.abi")
-    host = importlib.import_module("raytracer-rust_amd.host")
-    device = importlib.import_module("raytracer-rust_amd.device")
-    rtdist = importlib.import_module("raytracer-rust_amd.distributed")
-    build = importlib.import_module("raytracer-rust_amd.build")
+    abi, host, device, rtdist, build = product_modules()
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
@@ -225,6 +235,7 @@ def main():
         a, b, n = s["ctx"].read_timing()
         k_render_ms += a; k_resolve_ms += b; launches += n
         s["ctx"].set_timing(False)
+    my_elapsed = elapsed
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -237,84 +248,36 @@ def main():
     torch.cuda.synchronize()
     st = ctx0.render(slots[0]["local"].data_ptr(), None, opt, slots[0]["stream"].cuda_stream, want_stats=True)
     local_samples = n_local_rows * W * spp
-    rays_per_sample = st.rays / max(st.samples, 1)
     variant = ctx0.kernel_variant()
+    render_ms_per_step = k_render_ms / max(args.steps, 1)    # kernel time per STEP (= per full render of this rank's rows, all workspace bands together),
+    resolve_ms_per_step = k_resolve_ms / max(args.steps, 1)  # from the HIP events the library recorded around every launch of the timed region
+
+    # What proves that N ranks on N devices took part: every rank's identity and its own kernel time, collected with the process group.
+    ranks = None
+    if use_dist:
+        me = dict(device_identity(torch, local_rank), rank=rank, local_rank=local_rank, pid=os.getpid(), rows=n_local_rows,
+                  kernel_ms_per_step=round(render_ms_per_step, 4), resolve_ms_per_step=round(resolve_ms_per_step, 4),
+                  step_wall_ms=round(my_elapsed / max(args.steps, 1) * 1e3, 4), rays=int(st.rays))
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
 
     tail = None
     if args.tail_parts > 1 and world == 1:
-        tail = measure_tail(abi, rtdist, ctx0, slots[0], H, W, args.tail_parts, max(3, args.steps // 2), k_render_ms / max(args.steps, 1), torch)
+        tail = measure_tail(abi, rtdist, slots, H, W, args.tail_parts, max(3, args.steps // 2), render_ms_per_step, torch, device, scene, resolve_ms_per_step)
 
-    total_samples = W * H * spp
-    value = total_samples * args.steps / elapsed / 1e6
     result = None
     if rank == 0:
-        sc = scene.c
-        rec = sum(REC_BYTES[sc.primitives[i].kind] for i in range(sc.n_primitives))
-        nodes_per_ray = tris_per_ray = 0.0
-        cpu_baseline = None
-        try:                                   # the CPU leg must never cost the GPU measurement its JSON line
-            if world == 1 and args.cpu_seconds > 0:
-                cpu_baseline, nodes_per_ray, tris_per_ray = run_cpu_baseline(abi, scene, W, H, spp, args.cpu_seconds)
-            elif sc.n_meshes:
-                _, nodes_per_ray, tris_per_ray = run_cpu_baseline(abi, scene, W, H, spp, 0.5)
-        except Exception as e:                 # e.g. no g++ on the box
-            cpu_baseline = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-        # Kernel time per STEP (= per full render of this rank's rows, all workspace bands together), from the HIP events the
-        # library recorded around every launch of the timed region.
-        render_ms_per_step = k_render_ms / max(args.steps, 1)
-        resolve_ms_per_step = k_resolve_ms / max(args.steps, 1)
-        share = local_samples / total_samples            # a rank renders its strips only; counters were taken on the whole image
-        khash = build.kernel_hash()
-        pmc, pmc_state = load_pmc(args.workload, khash, KERNEL_NAMES.get(variant))
-        peak_inst = VALU_SIMDS * VALU_CLOCK_HZ / VALU_CYCLES_PER_WAVE64_INST
-        achieved = frac = lane_util = traffic = insts = None
-        hbm = None
-        if pmc and render_ms_per_step > 0:
-            insts = pmc["valu_wave_insts_per_step"] * share
-            achieved = insts / (render_ms_per_step * 1e-3)
-            frac = achieved / peak_inst
-            lane_util = pmc.get("valu_lane_utilisation")
-            traffic = int(pmc["hbm_bytes_per_step"] * share)
-            gbs = traffic / (render_ms_per_step * 1e-3) / 1e9
-            hbm = {"traffic_bytes": traffic, "achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
-                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB x 1024 per step; x2 = gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md, HBM)"}
-        bytes_per_sample = rays_per_sample * (rec + 48 + nodes_per_ray * 32 + tris_per_ray * 48) + 16.0 / spp
-        result = {
-            "metric": f"Msamples/s (pixels x spp / s) at {W}x{H}x{spp}spp; 1/2/4/8-GPU scaling",
-            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": f"synthetic (the reference's own scene file {path}; no external data)",
-            "config": {"workload": args.workload, "scene": path, "width": W, "height": H, "spp": spp, "max_bounces": depth,
-                       "rng": "ctr (Philox4x32-10 per ray)", "parallelism": f"row strips of {plan.strip_rows} dealt round-robin over {world} GPU(s)"
-                       + (f", RCCL {rtdist.collective_name(rehearse)} of the packed rows" if use_dist else ""),
-                       "frames_in_flight": depth_pipe},
-            "roofline": {"bound": "valu", "kernel": KERNEL_NAMES.get(variant, "k_render_ctr"),
-                         "achieved": None if achieved is None else round(achieved / 1e9, 1), "peak": round(peak_inst / 1e9, 1),
-                         "unit": "G wave-instructions/s", "frac": None if frac is None else round(frac, 4), "traffic": traffic,
-                         "lane_utilisation": lane_util,
-                         "wave_insts_per_step": None if achieved is None else int(insts),
-                         "wave_insts_per_ray": None if achieved is None or st.rays == 0 else round(insts * 64.0 / st.rays, 1),   # VALU instructions a wave issues per 64 rays
-                         "useful_frac": None if frac is None or lane_util is None else round(frac * lane_util, 4),
-                         "hbm": hbm,
-                         "kernel_ms_per_step": round(render_ms_per_step, 4), "resolve_ms_per_step": round(resolve_ms_per_step, 4),
-                         "kernel_launches_per_step": launches / max(args.steps, 1), "samples_per_step": local_samples,
-                         "pmc": pmc_state, "kernel_hash": khash,
-                         "logical_bytes_model": {"bytes_per_sample": round(bytes_per_sample, 1), "rays_per_sample": round(rays_per_sample, 4),
-                                                 "bytes_per_step": int(bytes_per_sample * local_samples),
-                                                 "note": "SURVEY.md 8d algorithmic bytes; SGPR/L2 resident, never reach HBM -- a model, not an HBM fraction"},
-                         "note": "achieved = SQ_INSTS_VALU per step (PMC, profiles/pmc_counters.json, same kernel hash) / live HIP-event kernel time per step; "
-                                 "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (nominal: a loop of nothing but independent "
-                                 "v_mul_f32 / v_add_f32 reaches 0.82-0.94 of it at a sustained 2.32-2.39 GHz -- tools/microbench/clock.hip, "
-                                 "profiles/r03_microbench_clock_and_issue.txt -- and v_fma / v_rcp / v_sqrt / 64-bit multiplies take more than one slot)"
-                                 + ("; frames overlap on two streams here, so the kernel's event time includes time it shared the chip" if depth_pipe > 1 else "")},
-            "cpu_baseline": cpu_baseline,
-            **({"tail": tail} if tail else {}),
-            **({"rehearsal": "all ranks on cuda:0 over gloo -- plumbing check only, NOT a measurement"} if rehearse else {}),
-            **({"forced_dist": "one rank through the RCCL branch (process group, barrier, all_gather_into_tensor, all_reduce) -- a check of the calls, not a multi-GPU measurement"} if use_dist and world == 1 else {}),
-            "kernel": {"vgprs": st.kernel_vgprs, "grid_blocks": st.grid_blocks, "block_threads": st.block_threads, "bands": st.bands},
-        }
-        if image_checksum is not None:
-            result["image_checksum"] = image_checksum
+        launch = os.environ.get("MI355RT_BENCH_LAUNCH") or ("external launcher (RANK / WORLD_SIZE were in the environment)" if "RANK" in os.environ else "direct: one process, one GPU")
+        dist_info = None
+        if use_dist:
+            dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
+                         "distinct_devices": len({(r["device_index"], r["pci_bus_id"]) for r in ranks})}
+        result = make_result(args, abi, build, rtdist, scene, plan, world, elapsed, render_ms_per_step, resolve_ms_per_step,
+                             launches / max(args.steps, 1), local_samples, st, variant, depth_pipe,
+                             gather=(f"RCCL {rtdist.collective_name(rehearse)} of the packed rows" if use_dist else ""),
+                             launch=launch, dist_info=dist_info, tail=tail, image_checksum=image_checksum,
+                             extras={**({"rehearsal": "all ranks on cuda:0 over gloo -- plumbing check only, NOT a measurement"} if rehearse else {}),
+                                     **({"forced_dist": "one rank through the RCCL branch (process group, barrier, all_gather_into_tensor, all_reduce) -- a check of the calls, not a multi-GPU measurement"} if use_dist and world == 1 else {})})
         if args.save_png and final_image is not None:
             import numpy as np
             host.write_png(args.save_png, final_image.cpu().numpy().astype(np.uint32), W, H)
@@ -327,10 +290,263 @@ def main():
     return result
 
 
-def measure_tail(abi, rtdist, ctx, slot, H, W, parts, steps, full_render_ms, torch):
+def product_modules():
+    return tuple(importlib.import_module("raytracer-rust_amd." + m) for m in ("abi", "host", "device", "distributed", "build"))
+
+
+def device_identity(torch, index):
+    """Which physical device a rank / a part ran on: index, name, PCI address (domain:bus:device), uuid where torch has them."""
+    p = torch.cuda.get_device_properties(index)
+    dom, bus, devid = getattr(p, "pci_domain_id", None), getattr(p, "pci_bus_id", None), getattr(p, "pci_device_id", None)
+    pci = None if bus is None else f"{dom if dom is not None else 0:04x}:{bus:02x}:{devid if devid is not None else 0:02x}"
+    return {"device_index": index, "device_name": p.name, "pci_bus_id": pci, "uuid": str(getattr(p, "uuid", "")) or None,
+            "visible_devices": torch.cuda.device_count()}
+
+
+def make_result(args, abi, build, rtdist, scene, plan, world, elapsed, render_ms_per_step, resolve_ms_per_step, launches_per_step,
+                local_samples, st, variant, depth_pipe, gather, launch, dist_info, tail, image_checksum, extras):
+    """The one JSON line (rank 0 / the single process).  `st` = stats of one untimed render of the caller's own rows (rays, grid);
+    render_ms_per_step / local_samples describe the same rows."""
+    path, W, H, spp, depth, _ = WORKLOADS[args.workload]
+    total_samples = W * H * spp
+    value = total_samples * args.steps / elapsed / 1e6
+    rays_per_sample = st.rays / max(st.samples, 1)
+    sc = scene.c
+    rec = sum(REC_BYTES[sc.primitives[i].kind] for i in range(sc.n_primitives))
+    nodes_per_ray = tris_per_ray = 0.0
+    cpu_baseline = None
+    try:                                   # the CPU leg must never cost the GPU measurement its JSON line
+        if world == 1 and args.cpu_seconds > 0:
+            cpu_baseline, nodes_per_ray, tris_per_ray = run_cpu_baseline(abi, scene, W, H, spp, args.cpu_seconds)
+        elif sc.n_meshes:
+            _, nodes_per_ray, tris_per_ray = run_cpu_baseline(abi, scene, W, H, spp, 0.5)
+    except Exception as e:                 # e.g. no g++ on the box
+        cpu_baseline = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    share = local_samples / total_samples            # a rank renders its strips only; counters were taken on the whole image
+    khash = build.kernel_hash()
+    pmc, pmc_state = load_pmc(args.workload, khash, KERNEL_NAMES.get(variant))
+    peak_inst = VALU_SIMDS * VALU_CLOCK_HZ / VALU_CYCLES_PER_WAVE64_INST
+    achieved = frac = lane_util = traffic = insts = None
+    hbm = None
+    if pmc and render_ms_per_step > 0:
+        insts = pmc["valu_wave_insts_per_step"] * share
+        achieved = insts / (render_ms_per_step * 1e-3)
+        frac = achieved / peak_inst
+        lane_util = pmc.get("valu_lane_utilisation")
+        traffic = int(pmc["hbm_bytes_per_step"] * share)
+        gbs = traffic / (render_ms_per_step * 1e-3) / 1e9
+        hbm = {"traffic_bytes": traffic, "achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
+               "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB x 1024 per step; x2 = gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md, HBM)"}
+    bytes_per_sample = rays_per_sample * (rec + 48 + nodes_per_ray * 32 + tris_per_ray * 48) + 16.0 / spp
+    result = {
+        "metric": f"Msamples/s (pixels x spp / s) at {W}x{H}x{spp}spp; 1/2/4/8-GPU scaling",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": f"synthetic (the reference's own scene file {path}; no external data)",
+        "config": {"workload": args.workload, "scene": path, "width": W, "height": H, "spp": spp, "max_bounces": depth,
+                   "rng": "ctr (Philox4x32-10 per ray)", "parallelism": f"row strips of {plan.strip_rows} dealt round-robin over {world} GPU(s)"
+                   + (f", {gather}" if gather else ""),
+                   "frames_in_flight": depth_pipe},
+        "launch": launch,
+        **({"distributed": dist_info} if dist_info else {}),
+        "roofline": {"bound": "valu", "kernel": KERNEL_NAMES.get(variant, "k_render_ctr"),
+                     "achieved": None if achieved is None else round(achieved / 1e9, 1), "peak": round(peak_inst / 1e9, 1),
+                     "unit": "G wave-instructions/s", "frac": None if frac is None else round(frac, 4), "traffic": traffic,
+                     "lane_utilisation": lane_util,
+                     "wave_insts_per_step": None if achieved is None else int(insts),
+                     "wave_insts_per_ray": None if achieved is None or st.rays == 0 else round(insts * 64.0 / st.rays, 1),   # VALU instructions a wave issues per 64 rays
+                     "useful_frac": None if frac is None or lane_util is None else round(frac * lane_util, 4),
+                     "hbm": hbm,
+                     "kernel_ms_per_step": round(render_ms_per_step, 4), "resolve_ms_per_step": round(resolve_ms_per_step, 4),
+                     "kernel_launches_per_step": launches_per_step, "samples_per_step": local_samples,
+                     "pmc": pmc_state, "kernel_hash": khash,
+                     "logical_bytes_model": {"bytes_per_sample": round(bytes_per_sample, 1), "rays_per_sample": round(rays_per_sample, 4),
+                                             "bytes_per_step": int(bytes_per_sample * local_samples),
+                                             "note": "SURVEY.md 8d algorithmic bytes; SGPR/L2 resident, never reach HBM -- a model, not an HBM fraction"},
+                     "note": "achieved = SQ_INSTS_VALU per step (PMC, profiles/pmc_counters.json, same kernel hash) / live HIP-event kernel time per step; "
+                             "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (nominal: a loop of nothing but independent "
+                             "v_mul_f32 / v_add_f32 reaches 0.82-0.94 of it at a sustained 2.32-2.39 GHz -- tools/microbench/clock.hip, "
+                             "profiles/r03_microbench_clock_and_issue.txt -- and v_fma / v_rcp / v_sqrt / 64-bit multiplies take more than one slot)"
+                             + ("; frames overlap on two streams here, so the kernel's event time includes time it shared the chip" if depth_pipe > 1 else "")
+                             + ("; kernel figures are those of rank / device 0's rows" if world > 1 else "")},
+        "cpu_baseline": cpu_baseline,
+        **({"tail": tail} if tail else {}),
+        **extras,
+        "kernel": {"vgprs": st.kernel_vgprs, "grid_blocks": st.grid_blocks, "block_threads": st.block_threads, "bands": st.bands},
+    }
+    if image_checksum is not None:
+        result["image_checksum"] = image_checksum
+    return result
+
+
+# ---------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` as typed: the parent process.  It imports neither torch nor the product and never touches a GPU.
+# ---------------------------------------------------------------------------------------------------
+def run_relay(cmd, env):
+    """Runs `cmd` as a child process, passes its stdout through line by line (stderr is inherited) and reports (exit code, whether a
+    result line -- a JSON object with "metric" -- went by)."""
+    import subprocess
+    saw = False
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    try:
+        for line in proc.stdout:
+            if line.lstrip().startswith("{") and '"metric"' in line:
+                saw = True
+            sys.stdout.write(line); sys.stdout.flush()
+        return proc.wait(), saw
+    except BaseException:
+        proc.kill(); proc.wait()
+        raise
+
+
+def launcher_command(n, argv):
+    """The command line of the one-rank-per-GPU launch: torch.distributed.run on 127.0.0.1 with a port that is free right now.
+    MI355RT_BENCH_LAUNCHER (a command prefix) replaces the launcher -- tests put a stub there and read back what it was given."""
+    import shlex
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    launcher = shlex.split(os.environ.get("MI355RT_BENCH_LAUNCHER", "")) or [sys.executable, "-m", "torch.distributed.run"]
+    return launcher + ["--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+
+
+def self_launch(args, argv):
+    n = max(1, args.gpus)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # before any child initialises HIP (see main)
+    env["MI355RT_BENCH_LAUNCH"] = f"self: bench.py --gpus {n} started torch.distributed.run ({n} fresh child process(es), 127.0.0.1)"
+    rc, saw = run_relay(launcher_command(n, argv), env)
+    if rc == 0 and saw:
+        return 0
+    if n > 1 and os.environ.get("MI355RT_BENCH_NO_FALLBACK") != "1":
+        why = f"ended with code {rc}" + ("" if saw else " and printed no result line")
+        print(f"bench.py: the {n}-rank launch {why}; starting ONE fresh process that drives all {n} devices (--single-process)", file=sys.stderr, flush=True)
+        env["MI355RT_BENCH_LAUNCH"] = f"fallback: one process drives {n} devices (--single-process) because the {n}-rank launch {why}"
+        rc2, saw2 = run_relay([sys.executable, os.path.abspath(__file__), *argv, "--single-process"], env)
+        return rc2 if (rc2 != 0 or saw2) else 1
+    return rc if rc != 0 else 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# --single-process: ONE process, N devices.  The strip plan, the contexts and the kernels are those of the rank path; the exchange step is
+# N device-to-device copies into device 0 (hipMemcpyPeerAsync under torch's copy_) instead of the RCCL all-gather, then the same index_select.
+# ---------------------------------------------------------------------------------------------------
+def main_single_process(args):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    abi, host, device, rtdist, build = product_modules()
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    n = max(1, args.gpus)
+    # MI355RT_BENCH_REHEARSE=1 on a one-GPU box: every part runs on cuda:0 (own context, buffers and stream each) -- a check of the plumbing.
+    rehearse = os.environ.get("MI355RT_BENCH_REHEARSE") == "1"
+    if not rehearse and torch.cuda.device_count() < n:
+        sys.exit(f"bench.py: --single-process --gpus {n} but only {torch.cuda.device_count()} device(s) are visible")
+    devs = [0 if rehearse else d for d in range(n)]
+    path, W, H, spp, depth, skip_unknown = WORKLOADS[args.workload]
+    scene = host.LoadedScene(os.path.join(ROOT, path), W, H, spp, depth, skip_unknown_primitives=skip_unknown)
+    plan = rtdist.make_plan(H, W, n)
+    depth_pipe = args.pipeline if args.pipeline > 0 else 2
+    parts = []                                               # parts[d] = that device's frame slots
+    for d in range(n):
+        with torch.cuda.device(devs[d]):
+            slots = []
+            for _ in range(depth_pipe):
+                ctx = device.Context(devs[d])
+                ctx.set_scene(scene, scene.camera, scene.settings)
+                slots.append({"ctx": ctx, "local": torch.zeros((plan.max_rows, W), dtype=torch.int32, device=f"cuda:{devs[d]}"),
+                              "stream": torch.cuda.Stream(device=devs[d]), "ready": torch.cuda.Event()})
+            parts.append({"slots": slots, "opt": plan.options_for(abi, d)})
+    dev0 = torch.device("cuda", devs[0])
+    stacked = [torch.empty((n * plan.max_rows, W), dtype=torch.int32, device=dev0) for _ in range(depth_pipe)]
+    gather_streams = [torch.cuda.Stream(device=dev0) for _ in range(depth_pipe)]
+    perm = plan.perm_on(dev0)
+    image = None
+    frame = 0
+
+    def step():
+        nonlocal image, frame
+        k = frame % depth_pipe
+        frame += 1
+        for d in range(n):                                    # every device's strips, enqueued without a host sync
+            s = parts[d]["slots"][k]
+            with torch.cuda.device(devs[d]), torch.cuda.stream(s["stream"]):
+                s["ctx"].render(s["local"].data_ptr(), None, parts[d]["opt"], s["stream"].cuda_stream)
+                s["ready"].record(s["stream"])
+        with torch.cuda.device(devs[0]), torch.cuda.stream(gather_streams[k]):
+            for d in range(n):                                # the exchange step: device d's packed rows -> its block of device 0's buffer
+                gather_streams[k].wait_event(parts[d]["slots"][k]["ready"])
+                stacked[k][d * plan.max_rows:(d + 1) * plan.max_rows].copy_(parts[d]["slots"][k]["local"], non_blocking=True)
+            image = stacked[k].index_select(0, perm)
+            done = torch.cuda.Event(); done.record(gather_streams[k])
+        for d in range(n):                                    # frame k + depth_pipe may not overwrite `local` before this gather has read it
+            parts[d]["slots"][k]["stream"].wait_event(done)
+
+    def sync_all():
+        for d in sorted(set(devs)):
+            torch.cuda.synchronize(d)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    for p in parts:
+        for s in p["slots"]:
+            s["ctx"].set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    per_part = []
+    for d, p in enumerate(parts):
+        a = b = 0.0; ln = 0
+        for s in p["slots"]:
+            try:
+                s["ctx"].check()
+            except device.RenderError as e:
+                sys.exit(f"bench.py: device {devs[d]}: a timed render did not complete -- {e}")
+            x, y, m = s["ctx"].read_timing()
+            a += x; b += y; ln += m
+            s["ctx"].set_timing(False)
+        per_part.append((a / max(args.steps, 1), b / max(args.steps, 1), ln / max(args.steps, 1)))
+    image_checksum = int(image.to(torch.int64).sum().item())
+    final_image = image.clone()
+    sync_all()
+    stats = []
+    for d, p in enumerate(parts):
+        s = p["slots"][0]
+        with torch.cuda.device(devs[d]):
+            stats.append(s["ctx"].render(s["local"].data_ptr(), None, p["opt"], s["stream"].cuda_stream, want_stats=True))
+    variant = parts[0]["slots"][0]["ctx"].kernel_variant()
+    ranks = [dict(device_identity(torch, devs[d]), part=d, pid=os.getpid(), rows=len(plan.rows[d]), kernel_ms_per_step=round(per_part[d][0], 4),
+                  resolve_ms_per_step=round(per_part[d][1], 4), rays=int(stats[d].rays)) for d in range(n)]
+    result = make_result(args, abi, build, rtdist, scene, plan, n, elapsed, per_part[0][0], per_part[0][1], per_part[0][2],
+                         len(plan.rows[0]) * W * spp, stats[0], variant, depth_pipe,
+                         gather=f"{n} device-to-device copies of the packed rows into device 0" if n > 1 else "",
+                         launch=os.environ.get("MI355RT_BENCH_LAUNCH") or "direct: --single-process",
+                         dist_info={"backend": "none (one process, hipMemcpyPeer)", "world_size": n, "ranks": ranks,
+                                    "distinct_devices": len({(r["device_index"], r["pci_bus_id"]) for r in ranks})},
+                         tail=None, image_checksum=image_checksum,
+                         extras={"rehearsal": "every part on cuda:0 -- plumbing check only, NOT a measurement"} if rehearse else {})
+    if args.save_png:
+        import numpy as np
+        host.write_png(args.save_png, final_image.cpu().numpy().astype(np.uint32), W, H)
+    print(json.dumps(result), flush=True)
+    for p in parts:
+        for s in p["slots"]:
+            s["ctx"].close()
+    return result
+
+
+def measure_tail(abi, rtdist, slots, H, W, parts, steps, full_render_ms, torch, device, scene, full_resolve_ms=0.0):
     """What ONE of `parts` GPUs would run: strip part p of `parts` of the same image, timed on this GPU for every p.
-    ideal = full-image kernel time / parts; the difference is the launch tail (waves draining their last paths)."""
+    ideal = full-image kernel time / parts; the difference is the launch tail (waves draining their last paths).
+    Then the same 1/P-image frames back to back on TWO streams (a context each), as bench.py runs them for N > 1: the next frame's
+    waves fill the CUs the draining frame leaves idle, so the steady-state time per frame is the honest per-GPU bound of the N-GPU line."""
     plan = rtdist.make_plan(H, W, parts)
+    slot = slots[0]
+    ctx = slot["ctx"]
     stream = slot["stream"].cuda_stream
     per_part = []
     for p in range(parts):
@@ -346,12 +562,42 @@ def measure_tail(abi, rtdist, ctx, slot, H, W, parts, steps, full_render_ms, tor
         a, b, _ = ctx.read_timing()
         ctx.set_timing(False)
         per_part.append((a / steps, b / steps, wall))
-    worst = max(per_part, key=lambda x: x[2])
+    worst_p = max(range(parts), key=lambda p: per_part[p][2])
+    worst = per_part[worst_p]
     ideal = full_render_ms / parts
+    # two frames in flight
+    pair = list(slots[:2])
+    made = []
+    while len(pair) < 2:
+        c = device.Context(slot["local"].device.index)
+        c.set_scene(scene, scene.camera, scene.settings)
+        extra = {"ctx": c, "local": torch.zeros_like(slot["local"]), "stream": torch.cuda.Stream(device=slot["local"].device)}
+        pair.append(extra); made.append(extra)
+    if pair[0]["stream"].cuda_stream == pair[1]["stream"].cuda_stream or pair[0]["stream"].cuda_stream == 0:
+        pair[0] = dict(pair[0], stream=torch.cuda.Stream(device=slot["local"].device))
+    o = plan.options_for(abi, worst_p)
+    for s in pair:
+        s["ctx"].render(s["local"].data_ptr(), None, o, s["stream"].cuda_stream)
+    torch.cuda.synchronize()
+    n2 = 2 * max(steps, 4)
+    t0 = time.perf_counter()
+    for i in range(n2):
+        s = pair[i & 1]
+        s["ctx"].render(s["local"].data_ptr(), None, o, s["stream"].cuda_stream)
+    torch.cuda.synchronize()
+    two = (time.perf_counter() - t0) / n2 * 1e3
+    for s in pair:
+        s["ctx"].check()
+    for e in made:
+        e["ctx"].close()
+    ideal_step = (full_render_ms + full_resolve_ms) / parts
     return {"parts": parts, "strip_rows": plan.strip_rows, "ideal_render_ms": round(ideal, 4),
             "render_ms_max": round(max(x[0] for x in per_part), 4), "render_ms_mean": round(sum(x[0] for x in per_part) / parts, 4),
             "resolve_ms_max": round(max(x[1] for x in per_part), 4), "step_wall_ms_max": round(worst[2], 4),
             "tail_efficiency": round(ideal / max(x[0] for x in per_part), 4),
+            "two_streams": {"part": worst_p, "ms_per_frame": round(two, 4), "ideal_ms_per_frame": round(ideal_step, 4),
+                            "efficiency": round(ideal_step / two, 4),
+                            "note": "1/P-image frames back to back on two streams (own context each), wall time per frame incl. resolve; ideal = (full-image render + resolve kernel ms) / P"},
             "note": "one GPU renders strip part p of P of the image, every p in turn (no gather): an upper bound for P-GPU strong scaling"}
 
 

@@ -13,6 +13,8 @@
 #include <limits>
 #include <map>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -26,6 +28,19 @@ namespace {
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
+int fail_noexcept(int code, const char* msg) noexcept { try { g_err.assign(msg); } catch (...) { g_err.clear(); } return code; }
+// The exception barrier of every extern "C" entry point below (mi355rt.h: "nothing aborts, nothing throws across the ABI"; the caller may
+// be a Rust frame -- src/renderer.rs:67 is called from src/main.rs:57 -- into which a C++ exception must not unwind):
+// std::bad_alloc / std::length_error -> MI355RT_ERR_OOM, anything else -> MI355RT_ERR_HIP with what() in mi355rt_last_error().
+template <class F> int guard(F&& f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail_noexcept(MI355RT_ERR_OOM, "host allocation failed (std::bad_alloc)"); }
+    catch (const std::length_error&) { return fail_noexcept(MI355RT_ERR_OOM, "host allocation failed (std::length_error)"); }
+    catch (const std::exception& e) {
+        try { return fail(MI355RT_ERR_HIP, std::string("unexpected C++ exception: ") + e.what()); } catch (...) { return fail_noexcept(MI355RT_ERR_HIP, "unexpected C++ exception"); }
+    }
+    catch (...) { return fail_noexcept(MI355RT_ERR_HIP, "unexpected C++ exception"); }
+}
 #define HIP_TRY(expr)                                                                              \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? MI355RT_ERR_OOM : MI355RT_ERR_HIP, \
          std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
@@ -461,6 +476,7 @@ extern "C" {
 // all defaults.  Knobs: kernel (KERNEL_* of rt_device.h, -1 = automatic), guided_mult, spin_idle, spin_entry, wave_times, and for the
 // reference build's kernels inline_steps, trav_min, walkers, pool_patience.
 int mi355rt_debug_set_knob(mi355rt_context* ctx, const char* name, int value) {
+    return guard([&]() -> int {
     if (ctx) return name ? apply_knob(ctx, name, value) : fail(MI355RT_ERR_INVALID, "knob name is null");
     std::lock_guard<std::mutex> g(g_knob_mutex);
     if (!name) { g_default_knobs.clear(); return MI355RT_OK; }
@@ -468,6 +484,7 @@ int mi355rt_debug_set_knob(mi355rt_context* ctx, const char* name, int value) {
     const int rc = apply_knob(&probe, name, value);
     if (rc == MI355RT_OK) g_default_knobs[name] = value;
     return rc;
+    });
 }
 // 1 when this library holds the counter-mode kernel `variant` (the retired mesh kernels exist in the reference build only)
 int mi355rt_debug_has_variant(uint32_t variant) { return render_ctr_variant_built(variant) ? 1 : 0; }
@@ -476,14 +493,17 @@ const char* mi355rt_last_error(void) { return g_err.c_str(); }
 uint32_t mi355rt_abi_version(void) { return MI355RT_ABI_VERSION; }
 
 int mi355rt_rows_selected(const mi355rt_settings* settings, const mi355rt_options* options, uint32_t* out_rows) {
+    return guard([&]() -> int {
     int rc = check_settings(settings); if (rc) return rc;
     if (!out_rows) return fail(MI355RT_ERR_INVALID, "out_rows is null");
     RowSel sel; rc = select_rows(*settings, options, sel); if (rc) return rc;
     *out_rows = (uint32_t)sel.rows.size();
     return MI355RT_OK;
+    });
 }
 
 int mi355rt_context_create(int hip_device, mi355rt_context** out_ctx) {
+    return guard([&]() -> int {
     if (!out_ctx) return fail(MI355RT_ERR_INVALID, "out_ctx is null");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MI355RT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
@@ -511,9 +531,10 @@ int mi355rt_context_create(int hip_device, mi355rt_context** out_ctx) {
         for (const auto& kv : g_default_knobs) (void)apply_knob(ctx, kv.first, kv.second); }
     *out_ctx = ctx;
     return MI355RT_OK;
+    });
 }
 
-void mi355rt_context_destroy(mi355rt_context* ctx) {
+void mi355rt_context_destroy(mi355rt_context* ctx) {                 // (nothing in here allocates or throws: HIP calls and destructors of PODs' containers)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     ctx->prims.release(); ctx->mats.release(); ctx->nodes.release(); ctx->tris.release(); ctx->rows.release();
@@ -531,6 +552,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
 
 int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, const mi355rt_camera* camera,
                               const mi355rt_settings* settings) {
+    return guard([&]() -> int {
     if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
     if (!camera) return fail(MI355RT_ERR_INVALID, "camera is null");
     int rc = check_settings(settings); if (rc) return rc;
@@ -565,6 +587,7 @@ int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, 
         ctx->variant = ((double)st.rays >= PROBE_RAYS_PER_PATH * (double)std::max<uint64_t>(st.samples, 1)) ? KERNEL_WAVEFRONT_MESHFREE : KERNEL_LOCKSTEP_NOSPEC;
     }
     return MI355RT_OK;
+    });
 }
 
 // Samples [s0, s1) of every selected pixel.  The classic call is (0, settings.spp, no accumulator).
@@ -735,45 +758,56 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
 
 int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, void* d_out_packed, void* d_out_linear,
                            void* hip_stream, mi355rt_stats* stats) {
+    return guard([&]() -> int {
     if (!ctx || !ctx->have_scene) return fail(MI355RT_ERR_INVALID, "context has no scene");
     return render_samples(ctx, opt, 0, ctx->settings.samples_per_pixel, nullptr, d_out_packed, d_out_linear, hip_stream, stats);
+    });
 }
 
 int mi355rt_context_render_progressive(mi355rt_context* ctx, const mi355rt_options* opt, uint32_t sample_begin, uint32_t sample_end,
                                        void* d_accum, void* d_out_packed, void* d_out_linear, void* hip_stream, mi355rt_stats* stats) {
+    return guard([&]() -> int {
     if (!d_accum) return fail(MI355RT_ERR_INVALID, "d_accum is null");
     if (sample_end <= sample_begin) return fail(MI355RT_ERR_INVALID, "sample_end must be greater than sample_begin");
     return render_samples(ctx, opt, sample_begin, sample_end, d_accum, d_out_packed, d_out_linear, hip_stream, stats);
+    });
 }
 
 // Diagnostic hook (not part of the public header): which counter-mode kernel set_scene selected (KERNEL_* in rt_device.h).
 int mi355rt_debug_kernel_variant(mi355rt_context* ctx, uint32_t* out) {
+    return guard([&]() -> int {
     if (!ctx || !out || !ctx->have_scene) return fail(MI355RT_ERR_INVALID, "context has no scene");
     *out = ctx->variant;
     return MI355RT_OK;
+    });
 }
 
 // Diagnostic hook (not part of the public header): the STATS_WORDS (40) raw device counters of the last render.
 int mi355rt_debug_read_counters(mi355rt_context* ctx, unsigned long long* out40) {
+    return guard([&]() -> int {
     if (!ctx || !out40 || !ctx->stats.p) return fail(MI355RT_ERR_INVALID, "no counters");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpy(out40, ctx->stats.p, STATS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MI355RT_OK;
+    });
 }
 
 int mi355rt_debug_read_wave_times(mi355rt_context* ctx, unsigned long long* out, uint32_t capacity_waves, uint32_t* n_waves) {
+    return guard([&]() -> int {
     if (!ctx || !out || !n_waves) return fail(MI355RT_ERR_INVALID, "null");
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n = std::min(capacity_waves, ctx->wave_times_n);
     if (n) HIP_TRY(hipMemcpy(out, ctx->wave_times.p, (size_t)n * WAVE_TIME_WORDS * 8, hipMemcpyDeviceToHost));
     *n_waves = n;
     return MI355RT_OK;
+    });
 }
 
 // Diagnostic hooks (not part of the public header): one Material::scatter / one HittableList::hit per record through the
 // device functions of the render kernels, on the context's resident scene.  Host pointers in and out; records are the
 // 16- / 6- / 12-word PODs of rt_device.h.
 int mi355rt_debug_scatter(mi355rt_context* ctx, const void* in_records, uint32_t n, void* out_records) {
+    return guard([&]() -> int {
     if (!ctx || !ctx->have_scene || !in_records || !out_records) return fail(MI355RT_ERR_INVALID, "debug_scatter: null / no scene");
     HIP_TRY(hipSetDevice(ctx->device));
     const DebugScatterIn* in = static_cast<const DebugScatterIn*>(in_records);
@@ -786,9 +820,11 @@ int mi355rt_debug_scatter(mi355rt_context* ctx, const void* in_records, uint32_t
     }
     d_in.release(); d_out.release();
     return rc;
+    });
 }
 
 int mi355rt_debug_hit(mi355rt_context* ctx, const void* in_rays, uint32_t n, void* out_records) {
+    return guard([&]() -> int {
     if (!ctx || !ctx->have_scene || !in_rays || !out_records) return fail(MI355RT_ERR_INVALID, "debug_hit: null / no scene");
     HIP_TRY(hipSetDevice(ctx->device));
     DevBuf<DebugHitIn> d_in; DevBuf<DebugHitOut> d_out;
@@ -800,15 +836,19 @@ int mi355rt_debug_hit(mi355rt_context* ctx, const void* in_rays, uint32_t n, voi
     }
     d_in.release(); d_out.release();
     return rc;
+    });
 }
 
 int mi355rt_context_set_timing(mi355rt_context* ctx, int enable) {
+    return guard([&]() -> int {
     if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
     ctx->timing = enable != 0; ctx->pool_used = 0; ctx->timed_launches = 0;
     return MI355RT_OK;
+    });
 }
 
 int mi355rt_context_read_timing(mi355rt_context* ctx, double* render_kernel_ms, double* resolve_kernel_ms, uint32_t* launches) {
+    return guard([&]() -> int {
     if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));
     double a = 0, c = 0;
@@ -824,17 +864,21 @@ int mi355rt_context_read_timing(mi355rt_context* ctx, double* render_kernel_ms, 
     if (launches) *launches = ctx->timed_launches;
     ctx->pool_used = 0; ctx->timed_launches = 0;
     return mi355rt_context_check(ctx);                               // the timed renders must also have been COMPLETE renders
+    });
 }
 
 int mi355rt_context_check(mi355rt_context* ctx) {
+    return guard([&]() -> int {
     if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->have_last) HIP_TRY(hipEventSynchronize(ctx->done));     // every render enqueued so far has finished and left its error word
     return report_device_error(ctx);
+    });
 }
 
 int mi355rt_render(const mi355rt_scene* scene, const mi355rt_camera* camera, const mi355rt_settings* settings,
                    const mi355rt_options* opt, uint32_t* out_packed, float* out_linear, mi355rt_stats* stats) {
+    return guard([&]() -> int {
     if (!out_packed) return fail(MI355RT_ERR_INVALID, "out_packed_rgb is null");
     int rc = check_settings(settings); if (rc) return rc;
     uint32_t n_rows = 0;
@@ -856,10 +900,11 @@ int mi355rt_render(const mi355rt_scene* scene, const mi355rt_camera* camera, con
     }
     if (d_packed) (void)hipFree(d_packed);
     if (d_linear) (void)hipFree(d_linear);
-    std::string keep = g_err;
+    std::string keep; keep.swap(g_err);                               // (destroy may overwrite the message of the failure being reported; swap never throws)
     mi355rt_context_destroy(ctx);
-    g_err = keep;
+    g_err.swap(keep);
     return rc;
+    });
 }
 
 // One host process, several GPUs (the shape of the reference's own host: a single `main`, src/main.rs:22-89).
@@ -870,6 +915,7 @@ int mi355rt_render(const mi355rt_scene* scene, const mi355rt_camera* camera, con
 int mi355rt_render_multi(const mi355rt_scene* scene, const mi355rt_camera* camera, const mi355rt_settings* settings,
                          const mi355rt_options* opt, const int* hip_devices, uint32_t n_devices,
                          uint32_t* out_packed, float* out_linear, mi355rt_stats* stats) {
+    return guard([&]() -> int {
     if (!out_packed) return fail(MI355RT_ERR_INVALID, "out_packed_rgb is null");
     if (!hip_devices || n_devices == 0) return fail(MI355RT_ERR_INVALID, "hip_devices is empty");
     int rc = check_settings(settings); if (rc) return rc;
@@ -886,14 +932,13 @@ int mi355rt_render_multi(const mi355rt_scene* scene, const mi355rt_camera* camer
 
     struct Part { int rc = MI355RT_OK; std::string err; mi355rt_stats st{}; };
     std::vector<Part> parts(n_devices);
-    auto work = [&](uint32_t d) {
+    auto work_body = [&](uint32_t d, mi355rt_context*& ctx, uint32_t*& d_packed, float*& d_linear) {
         Part& me = parts[d];
         mi355rt_options o = base; o.n_parts = n_devices; o.part = d;
         RowSel sel;
         if ((me.rc = select_rows(*settings, &o, sel))) { me.err = g_err; return; }
         if (sel.rows.empty()) return;
         const size_t npix = sel.rows.size() * (size_t)W;
-        mi355rt_context* ctx = nullptr; uint32_t* d_packed = nullptr; float* d_linear = nullptr;
         std::vector<uint32_t> h_packed(npix); std::vector<float> h_linear(out_linear ? npix * 3 : 0);
         me.rc = mi355rt_context_create(hip_devices[d], &ctx);
         if (!me.rc) me.rc = mi355rt_context_set_scene(ctx, scene, camera, settings);
@@ -908,14 +953,30 @@ int mi355rt_render_multi(const mi355rt_scene* scene, const mi355rt_camera* camer
             std::memcpy(out_packed + dst, h_packed.data() + j * W, (size_t)W * 4);
             if (out_linear) std::memcpy(out_linear + dst * 3, h_linear.data() + j * W * 3, (size_t)W * 12);
         }
+    };
+    // One part, on whatever thread runs it.  Nothing may leave this function by exception -- on a worker thread that would be
+    // std::terminate -- and the device buffers are released on every path.
+    auto work = [&](uint32_t d) noexcept {
+        mi355rt_context* ctx = nullptr; uint32_t* d_packed = nullptr; float* d_linear = nullptr;
+        const int rc = guard([&]() -> int { work_body(d, ctx, d_packed, d_linear); return MI355RT_OK; });
+        if (rc != MI355RT_OK && parts[d].rc == MI355RT_OK) { parts[d].rc = rc; try { parts[d].err = g_err; } catch (...) {} }
         if (d_packed) (void)hipFree(d_packed);
         if (d_linear) (void)hipFree(d_linear);
         if (ctx) mi355rt_context_destroy(ctx);
     };
+    // One host thread per further device.  A thread that cannot be had (std::system_error: EAGAIN under a thread / process limit) is not
+    // an error: that part is rendered on the calling thread instead, after the threads that did start have been joined -- a joinable
+    // std::thread must never be destroyed (std::terminate).
     std::vector<std::thread> threads;
-    for (uint32_t d = 1; d < n_devices; ++d) threads.emplace_back(work, d);
+    std::vector<uint32_t> inline_parts;
+    try { threads.reserve(n_devices); } catch (...) {}
+    for (uint32_t d = 1; d < n_devices; ++d) {
+        try { threads.emplace_back(work, d); }
+        catch (...) { try { inline_parts.push_back(d); } catch (...) { for (auto& t : threads) t.join(); throw; } }
+    }
     work(0);
     for (auto& t : threads) t.join();
+    for (uint32_t d : inline_parts) work(d);
 
     mi355rt_stats total{};
     for (uint32_t d = 0; d < n_devices; ++d) {
@@ -930,12 +991,14 @@ int mi355rt_render_multi(const mi355rt_scene* scene, const mi355rt_camera* camer
     }
     if (stats) *stats = total;
     return MI355RT_OK;
+    });
 }
 
 // Host-buffer progressive render: what a preview window (src/main.rs:60-75) would be fed from.
 int mi355rt_render_progressive(const mi355rt_scene* scene, const mi355rt_camera* camera, const mi355rt_settings* settings,
                                const mi355rt_options* opt, uint32_t chunk_spp, mi355rt_progress_fn on_chunk, void* user,
                                uint32_t* out_packed, float* out_linear, mi355rt_stats* stats) {
+    return guard([&]() -> int {
     if (!out_packed) return fail(MI355RT_ERR_INVALID, "out_packed_rgb is null");
     if (chunk_spp == 0) return fail(MI355RT_ERR_INVALID, "chunk_spp is 0");
     int rc = check_settings(settings); if (rc) return rc;
@@ -976,10 +1039,11 @@ int mi355rt_render_progressive(const mi355rt_scene* scene, const mi355rt_camera*
     if (d_packed) (void)hipFree(d_packed);
     if (d_linear) (void)hipFree(d_linear);
     if (d_accum) (void)hipFree(d_accum);
-    std::string keep = g_err;
+    std::string keep; keep.swap(g_err);                               // (destroy may overwrite the message of the failure being reported; swap never throws)
     mi355rt_context_destroy(ctx);
-    g_err = keep;
+    g_err.swap(keep);
     return rc;
+    });
 }
 
 }  // extern "C"

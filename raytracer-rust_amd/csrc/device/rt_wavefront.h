@@ -38,6 +38,18 @@
 #ifndef MI355RT_AB_WF_WIDE
 #define MI355RT_AB_WF_WIDE true
 #endif
+#ifndef MI355RT_WF_WALK_MIN_ACTIVE
+#define MI355RT_WF_WALK_MIN_ACTIVE 0                        // a WALK pass ends at a round boundary once fewer than this many of its walks are unfinished (0: runs its rounds)
+#endif
+#ifndef MI355RT_WF_UNIFORM_WALK
+#define MI355RT_WF_UNIFORM_WALK 0                           // WALK reads the mesh record through scalar loads when every slot of the pass is in the same mesh
+#endif
+#ifndef MI355RT_WF_CLASS_SHADE
+#define MI355RT_WF_CLASS_SHADE 0                            // SHADE bodies per material class: 0 one body, 1 terminal | rest, 2 one per class
+#endif
+#ifndef MI355RT_WF_UNIFORM_FINISH
+#define MI355RT_WF_UNIFORM_FINISH 0                         // SHADE builds the hit record per distinct primitive of the pass from a scalar record
+#endif
 
 namespace mi355rt {
 
@@ -286,6 +298,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
     Prof prof; prof.begin();
     bool failed = false;
 #ifdef MI355RT_STAMPS
+    const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_dry = 0ull; uint32_t passes_after_dry = 0, alive_at_dry = 0;
     unsigned long long w_exec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w_lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // passes and slots per pass: 0 WALK, 1 TOP1, 2 walks parked by a TOP pass, 3 SHADE (+ free fill),
                                                                                                         // 4 box-test steps of WALK passes (lanes stepping), 5 leaf phases (lanes with a leaf), 6 WALK passes (walks finished), 7 inline steps in TOP
 #define MI355RT_WFCOUNT(i, n) do { w_exec[i] += 1; w_lanes[i] += (n); } while (0)
@@ -385,6 +399,12 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         // dealt (material read, radiance store, cursor atomic), and the top-level list runs at 1 rather than 0:
         // semesterbild 27.36 -> 27.25, teapot 16.44 -> 16.34, veach-mis 15.86 -> 15.66 (profiles/r03_ab_wavefront_wave_priority2.txt).
         __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_SCHED);
+#ifdef MI355RT_STAMPS
+        if (wc.exhausted()) {                              // all work dealt: from here on the workgroup only finishes the paths it holds
+            if (t_dry == 0ull) { t_dry = __builtin_amdgcn_s_memrealtime(); alive_at_dry = __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            ++passes_after_dry;
+        }
+#endif
         if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[17], 1u); break; }
         if (__hip_atomic_load(&Q.ctrl[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
         const uint32_t cT1 = HAS_MESH ? Q.count(WQ_TOP1) : 0u, cW = HAS_MESH ? Q.count(WQ_WALK) : 0u;
@@ -468,10 +488,42 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             bool live = have;
             const bool any_hit = have && c.idx != CAND_NONE;
             Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
+#if MI355RT_WF_UNIFORM_FINISH
+            if constexpr (HAS_MESH || MI355RT_WF_UNIFORM_FINISH >= 2) {
+                // One round per distinct winner among the pass's slots, each from a scalar record (the kind is then a scalar branch): a list has
+                // a handful of primitives and a class-sorted pass meets few of them.
+                uint64_t rem = __ballot(any_hit);
+                while (rem != 0ull) {
+                    const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)c.idx, (int)__builtin_ctzll(rem));
+                    const bool mine = any_hit && c.idx == i0;
+                    cprim_t pr = prims + i0;
+                    if (mine) finish_hit_at<HAS_MESH, HAS_MESH ? MI355RT_AB_WF_SHARED_TAIL : true>(pr, P.tris, c, ps.ro, ps.rd, h);
+                    rem &= ~__ballot(mine);
+                }
+            } else
+#endif
             if (any_hit) finish_hit<HAS_MESH, HAS_MESH ? MI355RT_AB_WF_SHARED_TAIL : true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
             // (the priority stays raised through the material read, the radiance store and the work cursor's atomic: shade_and_regenerate
             // drops it to 0 where the arithmetic starts, DROP_PRIO; the list walk below reads primitives again and runs at PRIO_TOP)
+#if MI355RT_WF_CLASS_SHADE
+            {   // `stage` is wave-uniform and the SHADE queues are sorted by material class: each class runs a body instantiated for its kinds only
+                // (scalar branch).  The terminal-class pass -- misses, emitters, free slots -- holds no scatter code at all.
+                [[maybe_unused]] constexpr uint32_t M_DIFF = MATS & MATS_DIFFUSE & ~MATS_TERMINAL, M_ROUGH = MATS & MATS_ROUGH;
+                [[maybe_unused]] constexpr uint32_t M_SPEC = MATS & (MATBIT(MI355RT_MAT_METAL) | MATBIT(MI355RT_MAT_DIELECTRIC));
+#define MI_SHADE(M) shade_and_regenerate<(M), MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true, false, MI355RT_AB_FASTN_WF>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof)
+                if (stage == WQ_SHADE) MI_SHADE(MATS & MATS_TERMINAL);
+#if MI355RT_WF_CLASS_SHADE >= 2
+                else if (stage == WQ_SHADE + 1u) { if constexpr (M_DIFF != 0u) MI_SHADE(M_DIFF); }         // (a class the set does not hold never has a queue entry)
+                else if (stage == WQ_SHADE + 2u) { if constexpr (M_ROUGH != 0u) MI_SHADE(M_ROUGH); }
+                else { if constexpr (M_SPEC != 0u) MI_SHADE(M_SPEC); }
+#else
+                else MI_SHADE(MATS);
+#endif
+#undef MI_SHADE
+            }
+#else
             shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true, false, MI355RT_AB_FASTN_WF>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
+#endif
             if (live) Slot::store_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index);    // a ray to trace: continuing or freshly generated
             const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
             if (lane == 0 && born != died) atomicAdd(&Q.ctrl[16], (uint32_t)(born - died));
@@ -500,6 +552,24 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             MeshTrav m; m.ro = mk(0, 0, 0); m.rd = mk(0, 0, 1); m.ix = m.iy = m.iz = 0.f; m.len_raw = 0.f; m.node = NODE_END; m.best_t = 0.f;
             m.best_tri = 0xFFFFFFFFu; m.leaf_a = m.leaf_b = 0;
             WalkKeep wkeep; wkeep.aux = 0.f; wkeep.w1 = wkeep.w2 = wkeep.cursor_word = 0u;
+#if MI355RT_WF_UNIFORM_WALK
+            {   // The mesh a parked walk is in (the slot's list cursor) is the same for every slot of nearly every pass -- semesterbild has one
+                // mesh, teapot two -- so its record is read ONCE per wave through the constant address space (scalar loads, the matrix in
+                // SGPRs, as TOP reads it) instead of per lane (global loads from per-lane addresses); a pass whose slots are in different
+                // meshes takes the per-lane form.
+                f3 ro_w = mk(0, 0, 0), rd_w = mk(0, 0, 1); uint32_t cur = 0; WalkRec w; w.node = NODE_END; w.best_t = 0.f; w.best_tri = 0xFFFFFFFFu;
+                if (have) Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
+                const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);              // lane 0 holds a slot (n > 0)
+                if (__ballot(have && cur != cur0) == 0ull) {
+                    cprim_t pr = prims + cur0;
+                    if (have) mesh_setup<MI355RT_AB_FAST_MESH_WALK>(pr, ro_w, rd_w, 0.f, m);
+                } else if (have) {
+                    const DevPrim* __restrict__ pr = P.prims + cur;
+                    mesh_setup<MI355RT_AB_FAST_MESH_WALK>(pr, ro_w, rd_w, 0.f, m);
+                }
+                if (have) { m.node = w.node; m.best_t = w.best_t; m.best_tri = w.best_tri; }
+            }
+#else
             if (have) {
                 f3 ro_w, rd_w; uint32_t cur; WalkRec w;
                 Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
@@ -507,6 +577,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 mesh_setup<MI355RT_AB_FAST_MESH_WALK>(pr, ro_w, rd_w, 0.f, m);                                                      // the object-space ray, as TOP computed it
                 m.node = w.node; m.best_t = w.best_t; m.best_tri = w.best_tri;
             }
+#endif
 #if MI355RT_WF_SPEC
             // Speculative walk past a leaf.  In the reference's recursion a hit leaf is tested at once, because a triangle hit shrinks
             // t_max for every box that follows (bvh.rs:148-156).  Most leaf tests MISS, and then the walk goes on exactly as if the leaf
@@ -520,7 +591,13 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             // phases run nearly empty and cost more than the stalls they avoid -- +3 % / +7 %.)
             uint32_t resume = NODE_END; bool stalled = false;
             for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
-                if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
+                const uint64_t walking = __ballot(have && (m.leaf_b != 0u || m.node != NODE_END));
+                if (walking == 0ull) break;
+#if MI355RT_WF_WALK_MIN_ACTIVE > 0
+                // A pass whose walks have mostly finished hands the rest back to the queue (every pending leaf is tested at the end of a round, so a
+                // round boundary is a clean place to park): they come back in a full pass instead of stepping on at a fraction of the lanes.
+                if (round != 0 && (uint32_t)__popcll(walking) < (uint32_t)MI355RT_WF_WALK_MIN_ACTIVE) break;
+#endif
 #pragma unroll MI355RT_WF_UNROLL
                 for (int u = 0; u < MI355RT_WF_STEPS; ++u) {
                     const bool stepping = have && !stalled && m.node != NODE_END;
@@ -585,6 +662,13 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         }   // HAS_MESH
     }
     const uint32_t wp = wave_sum(n_paths), wr = wave_sum(n_rays);
+#ifdef MI355RT_STAMPS
+    if (P.wave_times && lane == 0) {                        // per wave: start, end, paths, the time its work cursor ran dry, loop turns after that, paths alive in the workgroup then
+        const unsigned long long t_wave1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* w = P.wave_times + WAVE_TIME_WORDS * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+        w[0] = t_wave0; w[1] = t_wave1; w[2] = wp; w[3] = t_dry ? t_dry : t_wave1; w[4] = passes_after_dry; w[5] = alive_at_dry;
+    }
+#endif
     if (lane == 0 && P.stats) {
         atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr);
 #ifdef MI355RT_STAMPS

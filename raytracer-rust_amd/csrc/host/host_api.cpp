@@ -4,6 +4,10 @@
 namespace mi355rt_host {
 namespace { thread_local std::string g_err; }
 int set_error(int code, const std::string& msg) { g_err = msg; return code; }
+int set_error_noexcept(int code, const char* msg) noexcept {
+    try { g_err.assign(msg); g_err += code == MI355RT_ERR_OOM ? ": host allocation failed" : ": unexpected C++ exception"; } catch (...) { g_err.clear(); }
+    return code;
+}
 const char* last_error() { return g_err.c_str(); }
 }  // namespace mi355rt_host
 

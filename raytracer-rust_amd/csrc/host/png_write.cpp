@@ -23,6 +23,7 @@ void chunk(std::vector<unsigned char>& out, const char type[4], const std::vecto
 
 extern "C" int mi355rt_write_png(const char* path, const uint32_t* packed, uint32_t width, uint32_t height) {
     using mi355rt_host::set_error;
+    return mi355rt_host::guard("write_png", MI355RT_ERR_IO, [&]() -> int {
     if (!path || !packed || width == 0 || height == 0) return set_error(MI355RT_ERR_INVALID, "write_png: bad argument");
     std::vector<unsigned char> raw((size_t)height * (1 + (size_t)width * 3));
     size_t o = 0;
@@ -47,12 +48,14 @@ extern "C" int mi355rt_write_png(const char* path, const uint32_t* packed, uint3
     const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
     std::fclose(f);
     return ok ? MI355RT_OK : set_error(MI355RT_ERR_IO, "write_png: short write");
+    });
 }
 
 // Linear f32 dump for parity tooling: Portable FloatMap, "PF", little-endian, rows BOTTOM-UP as
 // the format prescribes; `linear_rgb` is the pre-gamma mean image (row 0 = top) that mi355rt_render returns.
 extern "C" int mi355rt_write_pfm(const char* path, const float* linear_rgb, uint32_t width, uint32_t height) {
     using mi355rt_host::set_error;
+    return mi355rt_host::guard("write_pfm", MI355RT_ERR_IO, [&]() -> int {
     if (!path || !linear_rgb || width == 0 || height == 0) return set_error(MI355RT_ERR_INVALID, "write_pfm: bad argument");
     FILE* f = std::fopen(path, "wb");
     if (!f) return set_error(MI355RT_ERR_IO, std::string("write_pfm: cannot open ") + path);
@@ -61,6 +64,7 @@ extern "C" int mi355rt_write_pfm(const char* path, const float* linear_rgb, uint
         ok = std::fwrite(linear_rgb + (size_t)y * width * 3, sizeof(float), (size_t)width * 3, f) == (size_t)width * 3;
     std::fclose(f);
     return ok ? MI355RT_OK : set_error(MI355RT_ERR_IO, "write_pfm: short write");
+    });
 }
 
 // OpenEXR dump of the same image (SURVEY.md 8f-3 "f32/EXR dump"): single-part scan-line file, version 2, three FLOAT
@@ -69,6 +73,7 @@ extern "C" int mi355rt_write_pfm(const char* path, const float* linear_rgb, uint
 // value) closed by \0, one u64 offset per scan line, then per line: y, byte count, B row, G row, R row.
 extern "C" int mi355rt_write_exr(const char* path, const float* linear_rgb, uint32_t width, uint32_t height) {
     using mi355rt_host::set_error;
+    return mi355rt_host::guard("write_exr", MI355RT_ERR_IO, [&]() -> int {
     if (!path || !linear_rgb || width == 0 || height == 0 || width > (1u << 24) || height > (1u << 24)) return set_error(MI355RT_ERR_INVALID, "write_exr: bad argument");
     std::vector<unsigned char> h;
     auto u8 = [&](unsigned v) { h.push_back((unsigned char)v); };
@@ -89,6 +94,7 @@ extern "C" int mi355rt_write_exr(const char* path, const float* linear_rgb, uint
     attr("screenWindowWidth", "float", 4); f32(1.0f);
     u8(0);                                                            // end of header
     const uint64_t line_bytes = 8ull + 12ull * width, table = 8ull * height;
+    std::vector<float> row((size_t)3 * width);                        // (every allocation before the file is opened: nothing can throw past an open FILE*)
     FILE* f = std::fopen(path, "wb");
     if (!f) return set_error(MI355RT_ERR_IO, std::string("write_exr: cannot open ") + path);
     bool ok = std::fwrite(h.data(), 1, h.size(), f) == h.size();
@@ -97,7 +103,6 @@ extern "C" int mi355rt_write_exr(const char* path, const float* linear_rgb, uint
         unsigned char b[8]; for (int k = 0; k < 8; ++k) b[k] = (unsigned char)(off >> (8 * k));
         ok = std::fwrite(b, 1, 8, f) == 8;
     }
-    std::vector<float> row((size_t)3 * width);
     for (uint32_t y = 0; ok && y < height; ++y) {
         const float* src = linear_rgb + (size_t)y * width * 3;
         for (uint32_t x = 0; x < width; ++x) { row[x] = src[3 * x + 2]; row[(size_t)width + x] = src[3 * x + 1]; row[(size_t)2 * width + x] = src[3 * x]; }
@@ -106,4 +111,5 @@ extern "C" int mi355rt_write_exr(const char* path, const float* linear_rgb, uint
     }
     std::fclose(f);
     return ok ? MI355RT_OK : set_error(MI355RT_ERR_IO, "write_exr: short write");
+    });
 }

@@ -107,5 +107,8 @@ def test_bench_exports_the_ipc_mode_before_torch_is_imported():
     """RCCL's intra-node transport needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool (dmabuf IPC only); bench.py must have it in the
     environment before the HIP runtime comes up, i.e. textually before its `import torch`."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    body = src[src.index("def main():"):]
-    assert 0 < body.index('\n    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < body.index("\n    import torch\n")
+    for fn in ("def main(argv=None):", "def main_single_process(args):"):          # a rank under a launcher; one process driving every device
+        body = src[src.index(fn):]
+        assert 0 < body.index('\n    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < body.index("\n    import torch\n")
+    launch = src[src.index("def self_launch("):src.index("def main_single_process(")]    # the parent that starts the ranks: in the children's environment,
+    assert 'env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")' in launch and "import torch" not in launch   # and no torch in the parent at all

@@ -38,21 +38,65 @@ def test_multi_argument_checks(native, oracle_mod, abi):
         device.render_multi(sc, sc.camera, sc.settings, [])
 
 
-def test_bench_runs_its_rccl_branch_with_one_rank(tmp_path, native, abi):
-    """bench.py's multi-GPU branch (RCCL process group, barrier, all_gather_into_tensor on the launch stream, two frames in flight,
-    all_reduce of the step time) cannot run with two ranks on a one-GPU box -- RCCL refuses two ranks per device -- but it can run
-    with ONE: MI355RT_BENCH_FORCE_DIST=1 under torch.distributed.run.  The image must be the 1-GPU image (checksum)."""
+def _run_bench(args, **env_extra):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MI355RT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MI355RT_BENCH_FORCE_DIST", "MI355RT_BENCH_REHEARSE", "MI355RT_BENCH_LAUNCHER")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+def _one_gpu_checksum(native, abi, W, H, spp, depth):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host, device = native                                                    # the same frame through the plain one-GPU path
+    sc = host.LoadedScene(os.path.join(root, "data/scenes/tungsten/cornell-box/scene.json"), W, H, spp, depth)
+    return int(device.render(sc, sc.camera, sc.settings, abi.Options.make())[0].astype(np.int64).sum())
+
+
+def test_bench_runs_its_rccl_branch_with_one_rank(native, abi):
+    """bench.py's multi-GPU branch (RCCL process group, barrier, all_gather_into_tensor on the launch stream, two frames in flight,
+    all_reduce of the step time) cannot run with two ranks on a one-GPU box -- RCCL refuses two ranks per device -- but it can run
+    with ONE: MI355RT_BENCH_FORCE_DIST=1.  The command is the one the driver types, `python bench.py --gpus 1 ...`: bench.py starts
+    torch.distributed.run itself (self-launch) and relays the rank's line.  The image must be the 1-GPU image (checksum)."""
+    out, line = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"], MI355RT_BENCH_FORCE_DIST="1")
+    assert out.returncode == 0 and line, out.stderr[-2000:]
     assert line["forced_dist"] and line["n_gpus"] == 1 and line["config"]["frames_in_flight"] == 2
     assert "RCCL all-gather over xGMI" in line["config"]["parallelism"]
-    host, device = native                                                    # the same frame through the plain one-GPU path
-    sc = host.LoadedScene(os.path.join(root, "data/scenes/tungsten/cornell-box/scene.json"), 800, 600, 256, 30)
-    packed = device.render(sc, sc.camera, sc.settings, abi.Options.make())[0]
-    assert line["image_checksum"] == int(packed.astype(np.int64).sum())
+    assert line["launch"].startswith("self: bench.py --gpus 1 started torch.distributed.run")
+    d = line["distributed"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and len(d["ranks"]) == 1 and d["ranks"][0]["device_index"] == 0
+    assert d["ranks"][0]["kernel_ms_per_step"] > 0 and d["ranks"][0]["rows"] == 600
+    assert line["image_checksum"] == _one_gpu_checksum(native, abi, 800, 600, 256, 30)
+
+
+def test_bench_gpus_2_as_typed_starts_two_ranks(native, abi):
+    """`python bench.py --gpus 2` with no launcher around it: two fresh rank processes (rehearsal: both on cuda:0, the gather over gloo --
+    RCCL refuses two ranks on one device), one result line, the one-GPU image."""
+    out, line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--workload", "cornell-box-400x300x16-d4"], MI355RT_BENCH_REHEARSE="1")
+    assert out.returncode == 0 and line, out.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["rehearsal"] and line["launch"].startswith("self: bench.py --gpus 2")
+    d = line["distributed"]
+    assert d["world_size"] == 2 and [r["rank"] for r in d["ranks"]] == [0, 1] and d["ranks"][0]["pid"] != d["ranks"][1]["pid"]
+    assert all(r["rows"] == 150 and r["kernel_ms_per_step"] > 0 for r in d["ranks"])
+    assert line["image_checksum"] == _one_gpu_checksum(native, abi, 400, 300, 16, 4)
+
+
+def test_bench_single_process_mode_and_the_fallback_into_it(tmp_path, native, abi):
+    """--single-process: one process, a context + stream per device, device-to-device copies into device 0 (rehearsal: every part on cuda:0).
+    Reached directly, and as the fallback of `bench.py --gpus 2` when the rank launch fails (a stub launcher that exits 9)."""
+    import sys
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--workload", "cornell-box-400x300x16-d4"]
+    want = _one_gpu_checksum(native, abi, 400, 300, 16, 4)
+    out, line = _run_bench(args + ["--single-process"], MI355RT_BENCH_REHEARSE="1")
+    assert out.returncode == 0 and line, out.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["launch"] == "direct: --single-process" and line["image_checksum"] == want
+    assert line["distributed"]["world_size"] == 2 and [r["part"] for r in line["distributed"]["ranks"]] == [0, 1]
+    stub = tmp_path / "failing_launcher.py"
+    stub.write_text("import sys; sys.exit(9)\n")
+    out, line = _run_bench(args, MI355RT_BENCH_REHEARSE="1", MI355RT_BENCH_LAUNCHER=f"{sys.executable} {stub}")
+    assert out.returncode == 0 and line, out.stderr[-2000:]
+    assert line["launch"].startswith("fallback: one process drives 2 devices") and "ended with code 9" in line["launch"]
+    assert line["image_checksum"] == want and "device-to-device copies" in line["config"]["parallelism"]

@@ -16,9 +16,9 @@ out = torch.zeros(800 * 600, dtype=torch.int32, device="cuda")
 for parts in (1, 8):
     opt = abi.Options.make(strip_rows=5, n_parts=parts, part=0)
     for _ in range(3): st = ctx.render(out.data_ptr(), None, opt, None, want_stats=True)
-    buf = np.zeros(6 * 8192, np.uint64); n = C.c_uint32()
+    buf = np.zeros(6 * 16384, np.uint64); n = C.c_uint32()
     device.lib().mi355rt_debug_read_wave_times.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32, C.POINTER(C.c_uint32)]
-    assert device.lib().mi355rt_debug_read_wave_times(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 8192, C.byref(n)) == 0
+    assert device.lib().mi355rt_debug_read_wave_times(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 16384, C.byref(n)) == 0
     w = buf[:6 * n.value].reshape(-1, 6).astype(np.float64)
     t0 = w[:, 0].min(); start = (w[:, 0] - t0) / 100.0; end = (w[:, 1] - t0) / 100.0     # microseconds (100 MHz)
     print(f"parts={parts}: kernel {st.render_kernel_ms:.3f} ms, waves {n.value}, paths/wave mean {w[:,2].mean():.0f} min {w[:,2].min():.0f} max {w[:,2].max():.0f}")
@@ -32,3 +32,7 @@ for parts in (1, 8):
         *np.percentile(end - dry, [10, 50, 90, 100]), *np.percentile(w[:, 4], [50, 90, 100]), np.percentile(w[:, 5], 50)))
     d = end - dry; it = np.maximum(w[:, 4], 1)
     print("   us per drain iteration: p10 %.1f p50 %.1f p90 %.1f" % tuple(np.percentile(d / it, [10, 50, 90])))
+    # how much of the chip is still at work, and when: share of the waves alive at a few instants before the end
+    mk = end.max()
+    print("   waves still running at makespan - x: " + "  ".join(f"-{x} us: {(end > mk - x).mean():.3f}" for x in (100, 250, 500, 1000, 1500, 2000, 3000)))
+    print("   wave-time lost to the tail (waves x (makespan - end)) / (waves x makespan) = %.3f" % ((mk - end).sum() / (n.value * mk)))
