@@ -61,6 +61,29 @@ int select_rows(const mi355rt_settings& st, const mi355rt_options* o, RowSel& se
     return MI355RT_OK;
 }
 
+// The three row tables of one selection, n entries each: [0, n) natural = absolute y of local output row j; [n, 2n) processing = absolute y
+// of the row processed jp-th; [2n, 3n) out_row = the local output row that processing row jp is.  `cost` (per absolute image row, may be
+// empty) orders the processing: rows sorted by decreasing cost (stable: equal costs keep image order) and dealt round-robin over `groups`
+// consecutive ranges -- the launch's work shards (x bands) -- so that every range runs from its dearest rows to its cheapest.
+void row_tables(const std::vector<uint32_t>& rows, const std::vector<float>& cost, uint32_t groups, std::vector<uint32_t>& out) {
+    const size_t n = rows.size();
+    out.resize(3 * n);
+    std::vector<uint32_t> sorted(n);
+    for (size_t j = 0; j < n; ++j) sorted[j] = (uint32_t)j;
+    if (!cost.empty())
+        std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
+            const float ca = rows[a] < cost.size() ? cost[rows[a]] : 0.f, cb = rows[b] < cost.size() ? cost[rows[b]] : 0.f;
+            return ca > cb; });
+    groups = std::max(1u, std::min<uint32_t>(groups, (uint32_t)std::max<size_t>(n, 1)));
+    size_t jp = 0;
+    for (uint32_t g = 0; g < groups && !cost.empty(); ++g)
+        for (size_t k = g; k < n; k += groups, ++jp) { out[n + jp] = rows[sorted[k]]; out[2 * n + jp] = sorted[k]; }
+    for (size_t j = 0; j < n; ++j) {
+        out[j] = rows[j];
+        if (cost.empty()) { out[n + j] = rows[j]; out[2 * n + j] = (uint32_t)j; }
+    }
+}
+
 int check_settings(const mi355rt_settings* st) {
     if (!st) return fail(MI355RT_ERR_INVALID, "settings is null");
     if (st->width == 0 || st->height == 0 || st->samples_per_pixel == 0) return fail(MI355RT_ERR_INVALID, "width/height/spp must be > 0");
@@ -95,7 +118,7 @@ template <class T> struct DevBuf {
 }  // namespace
 
 struct mi355rt_context;
-static int report_device_error(mi355rt_context* ctx);
+static int report_device_error(mi355rt_context* ctx, bool this_render = false);
 
 struct mi355rt_context {
     int device = 0;
@@ -118,8 +141,17 @@ struct mi355rt_context {
     DevBuf<float> sky; uint32_t sky_w = 0, sky_h = 0;      // equirect HDR skybox (renderer.rs:40-54); sky_w == 0: none
     DevBuf<DevTexture> textures; DevBuf<uint32_t> texels;  // MI355RT_MAT_TEXTURE images: table + all texels in one buffer
     DevBuf<unsigned long long> wave_times; uint32_t wave_times_n = 0;   // diagnostics (MI355RT_WAVE_TIMES=1)
-    std::vector<uint32_t> rows_host;     // source of the async row-table upload; must outlive the copy
-    bool rows_valid = false;             // ctx->rows already holds rows_host (same selection as the last call)
+    std::vector<uint32_t> rows_host;     // the selected rows (absolute y, ascending = the order of the output buffer)
+    std::vector<uint32_t> tables_host;   // source of the async upload of the three row tables (row_tables()); must outlive the copy
+    bool rows_valid = false;             // ctx->rows already holds the tables of rows_host (same selection and grouping as the last call)
+    // Processing order (an experiment of round 4, opt-in).  The persistent kernels hand out a band's samples front to back, and a
+    // launch ends with the paths of the rows handed out LAST.  The idea: process the rows in order of DECREASING expected cost -- cheap rows
+    // (sky) last -- dealt over the work shards so that every shard ends with cheap rows, and a launch does not end on its longest paths.  The image cannot change: draws are keyed by absolute row / x /
+    // sample, the resolve kernel writes each pixel where it belongs (ResolveParams.out_row).  `row_cost` = rays per path of each image
+    // row, measured by set_scene with a small probe render of the same view; empty = natural order.
+    std::vector<float> row_cost;
+    int knob_row_order = -1;             // diagnostic knob "row_order": 1 on; -1 / 0 off (NOT shipped as a default: no measured gain, see set_scene)
+    uint32_t order_groups = 0;           // how many groups the cached tables were dealt over (work shards x bands)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // The workspaces (rows, radiance, counters, stats) belong to one render at a time.  `done` is recorded behind the last
     // operation of every render; a render enqueued on ANOTHER stream waits on it first, so two streams can never touch
@@ -133,6 +165,7 @@ struct mi355rt_context {
     // this context -- compares it with what has been reported and returns MI355RT_ERR_HIP once per failed render.
     DevBuf<unsigned long long> errword; unsigned long long* h_err = nullptr; unsigned long long err_reported = 0;
     uint32_t spin_limit_idle = SPIN_LIMIT_IDLE, spin_limit_entry = SPIN_LIMIT_ENTRY;   // diagnostic knobs "spin_idle" / "spin_entry"
+    uint32_t launched_variants = 0;      // bit v: kernel variant v was launched since the last failure report (names the kernel in the message)
     int forced_variant = -1;             // diagnostic knob "kernel": applied by set_scene when the scene allows it
     int knob_inline_steps = -1;          // diagnostic knob "inline_steps" (reference build's state machine / pool kernels)
     // timing pool (mi355rt_context_set_timing): event triples recorded around every kernel pair without
@@ -149,13 +182,28 @@ struct mi355rt_context {
 // Compares the host copy of the context's error word with what has already been reported.  The copy is refreshed in stream order
 // behind every render, so after a wait on `done` it covers every render enqueued so far; without a wait it covers those that
 // have finished.
-static int report_device_error(mi355rt_context* ctx) {
+// `this_render`: the caller has just waited for the render it enqueued itself (the stats path), so the failure is that render's; otherwise it
+// belongs to an earlier, asynchronous render on this context.  The word names the kernel(s) and the wait(s) that gave up (rt_device.h, err_tag).
+static int report_device_error(mi355rt_context* ctx, bool this_render) {
     if (!ctx->h_err) return MI355RT_OK;
     const unsigned long long now = *(volatile unsigned long long*)ctx->h_err;
-    if (now == ctx->err_reported) return MI355RT_OK;
-    const unsigned long long n = now - ctx->err_reported;
-    ctx->err_reported = now;
-    return fail(MI355RT_ERR_HIP, "kernel watchdog: " + std::to_string(n) + " wave(s) waited too long in an earlier render on this context and gave up -- that image is incomplete");
+    const unsigned long long count = now & 0xFFFFFFFFull;
+    if (count == ctx->err_reported) return MI355RT_OK;
+    const unsigned long long n = count - ctx->err_reported;
+    ctx->err_reported = count;
+    static const char* const kernel_names[KERNEL_VARIANTS] = {"k_render_ctr_nomesh", "k_render_ctr_mesh", "k_render_ctr_sm", "k_render_ctr_simple", "k_render_ctr_sm_fixaabb",
+        "k_render_ctr_pool", "k_render_ctr_pool_fixaabb", "k_render_ctr_wf", "k_render_ctr_wf_fixaabb", "k_render_ctr_nospec", "k_render_ctr_wf_nometal", "k_render_ctr_wf_meshfree"};
+    static const struct { uint32_t bit; const char* what; } waits[] = {
+        {WAIT_WF_IDLE, "idle: no progress in the workgroup"}, {WAIT_WF_RING, "ring entry: a reserved ticket was never written, or an entry never emptied"},
+        {WAIT_WF_FOLLOWED, "waves that followed their workgroup's error flag out"},
+        {WAIT_POOL_RESULTS, "pool producer: walk results did not come back"}, {WAIT_POOL_WALKER_IDLE, "pool walker: neither requests nor progress"}};
+    std::string kernels, which;
+    for (uint32_t v = 0; v < KERNEL_VARIANTS; ++v) if ((ctx->launched_variants >> v) & 1u) kernels += std::string(kernels.empty() ? "" : ", ") + kernel_names[v] + " (variant " + std::to_string(v) + ")";
+    ctx->launched_variants = 0;
+    for (const auto& w : waits) if ((now >> 32) & w.bit) which += std::string(which.empty() ? "" : "; ") + w.what;
+    return fail(MI355RT_ERR_HIP, "kernel watchdog: " + std::to_string(n) + " wave(s) gave up a bounded wait " + (this_render ? "in this render" : "in an earlier render on this context") +
+                                 " -- that image is incomplete [kernel(s) launched on this context since the last report: " + (kernels.empty() ? "?" : kernels) + "; wait: " + (which.empty() ? "?" : which) +
+                                 "; limits: " + std::to_string(ctx->spin_limit_idle) + " idle polls, " + std::to_string(ctx->spin_limit_entry) + " polls of a ring entry]");
 }
 
 namespace {
@@ -463,6 +511,7 @@ int apply_knob(mi355rt_context* ctx, const std::string& name, int v) {
     else if (name == "spin_idle") { if (v < 1) return fail(MI355RT_ERR_INVALID, "knob spin_idle"); ctx->spin_limit_idle = (uint32_t)v; }
     else if (name == "spin_entry") { if (v < 1) return fail(MI355RT_ERR_INVALID, "knob spin_entry"); ctx->spin_limit_entry = (uint32_t)v; }
     else if (name == "wave_times") ctx->want_wave_times = v != 0;
+    else if (name == "row_order") { if (v < -1 || v > 1) return fail(MI355RT_ERR_INVALID, "knob row_order"); ctx->knob_row_order = v; }
     else return fail(MI355RT_ERR_INVALID, "unknown knob " + name);
     return MI355RT_OK;
 }
@@ -548,7 +597,7 @@ void mi355rt_context_destroy(mi355rt_context* ctx) {                 // (nothing
 }
 
 static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint32_t s0, uint32_t s1, void* d_accum,
-                          void* d_out_packed, void* d_out_linear, void* hip_stream, mi355rt_stats* stats);
+                          void* d_out_packed, void* d_out_linear, void* hip_stream, mi355rt_stats* stats, unsigned long long* d_row_counters = nullptr);
 
 int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, const mi355rt_camera* camera,
                               const mi355rt_settings* settings) {
@@ -563,6 +612,9 @@ int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, 
     std::memcpy(&ctx->cam, camera, sizeof(DevCamera));
     ctx->settings = *settings;
     ctx->have_scene = true;
+    // The probe renders below are set_scene's own business: they stay out of the caller's timing pool (mi355rt_context_set_timing).
+    struct TimingOff { mi355rt_context* c; bool was; ~TimingOff() { c->timing = was; } } timing_off{ctx, ctx->timing};
+    ctx->timing = false;
     // The materials only say that the mesh-free wavefront kernel MAY pay (a rough conductor next to another scattering material).  Whether
     // it does depends on how much the paths scatter: veach-mis bounces 1.5 times per path and gains 13 %; a scene of the same materials that is
     // mostly sky (1.1 rays per path) has nothing to sort and lost 14 % to the queues (profiles/r03_ab_meshfree_wavefront_fuzz_scenes.txt).
@@ -586,13 +638,49 @@ int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, 
         if (rc) { ctx->have_scene = false; return rc; }
         ctx->variant = ((double)st.rays >= PROBE_RAYS_PER_PATH * (double)std::max<uint64_t>(st.samples, 1)) ? KERNEL_WAVEFRONT_MESHFREE : KERNEL_LOCKSTEP_NOSPEC;
     }
+    // Row costs for the processing order (see mi355rt_context::row_cost): the same view at <= 64 x 96 pixels, 4 samples per pixel, one small
+    // launch per probe row with its own {paths, rays} counters, all enqueued back to back and read after ONE wait -- deterministic (counter
+    // RNG), a few milliseconds, and only for frames large enough for the tail of a launch to matter (or when the knob asks).
+    ctx->row_cost.clear();
+    const uint64_t frame_samples = (uint64_t)ctx->settings.width * ctx->settings.height * ctx->settings.samples_per_pixel;
+    (void)frame_samples;
+    if (ctx->knob_row_order == 1) {                                       // measured (profiles/r04/ab_processing_order.txt): +-0.5 % on full frames -- the tail of a launch is old
+                                                                          // paths that waited in thin queues, not the rows handed out last -- so only the knob turns it on
+        const mi355rt_settings full = ctx->settings;
+        mi355rt_settings probe = full;
+        probe.width = std::min(full.width, 64u);
+        probe.height = std::min(full.height, 96u);
+        probe.samples_per_pixel = std::min(full.samples_per_pixel, 4u);
+        uint32_t* d_tmp = nullptr; unsigned long long* d_cnt = nullptr;
+        std::vector<unsigned long long> h_cnt(STATS_WORDS * (size_t)probe.height);
+        if (hipMalloc((void**)&d_tmp, (size_t)probe.width * probe.height * 4) != hipSuccess || hipMalloc((void**)&d_cnt, h_cnt.size() * 8) != hipSuccess ||
+            hipMemset(d_cnt, 0, h_cnt.size() * 8) != hipSuccess) {
+            if (d_tmp) (void)hipFree(d_tmp);
+            if (d_cnt) (void)hipFree(d_cnt);
+            ctx->have_scene = false; return fail(MI355RT_ERR_OOM, "hipMalloc(row probe)");
+        }
+        ctx->settings = probe;
+        rc = render_samples(ctx, nullptr, 0, probe.samples_per_pixel, nullptr, d_tmp, nullptr, nullptr, nullptr, d_cnt);
+        if (!rc && hipMemcpy(h_cnt.data(), d_cnt, h_cnt.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI355RT_ERR_HIP, "row probe: copy back");   // (waits for the launches)
+        if (!rc) rc = report_device_error(ctx);
+        (void)hipFree(d_tmp); (void)hipFree(d_cnt);
+        ctx->settings = full; ctx->rows_valid = false;
+        if (rc) { ctx->have_scene = false; return rc; }
+        ctx->row_cost.resize(full.height);
+        for (uint32_t y = 0; y < full.height; ++y) {
+            const uint32_t i = (uint32_t)std::min<uint64_t>(probe.height - 1, (uint64_t)y * probe.height / full.height);
+            ctx->row_cost[y] = (float)((double)h_cnt[STATS_WORDS * (size_t)i + 1] / (double)std::max<unsigned long long>(h_cnt[STATS_WORDS * (size_t)i], 1ull));
+        }
+    }
     return MI355RT_OK;
     });
 }
 
 // Samples [s0, s1) of every selected pixel.  The classic call is (0, settings.spp, no accumulator).
+// d_row_counters (set_scene's row-cost probe only): one launch per selected ROW, each with its own block of device counters ({paths, rays, ...})
+// at d_row_counters + STATS_WORDS * row, nothing resolved, nothing waited for.
 static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint32_t s0, uint32_t s1, void* d_accum,
-                          void* d_out_packed, void* d_out_linear, void* hip_stream, mi355rt_stats* stats) {
+                          void* d_out_packed, void* d_out_linear, void* hip_stream, mi355rt_stats* stats, unsigned long long* d_row_counters) {
     if (!ctx || !ctx->have_scene) return fail(MI355RT_ERR_INVALID, "context has no scene");
     if (!d_out_packed) return fail(MI355RT_ERR_INVALID, "d_out_packed is null");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -601,13 +689,24 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
     const mi355rt_settings& st = ctx->settings;
     RowSel sel; int rc = select_rows(st, opt, sel); if (rc) return rc;
     if (ctx->have_last && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->done, 0));   // the previous render owned the workspaces
-    const bool same_rows = ctx->rows_valid && sel.rows == ctx->rows_host;
+    const uint32_t rng_mode = opt ? opt->rng_mode : (uint32_t)MI355RT_RNG_CTR;
+    // How many consecutive ranges the processing order is dealt over: the work shards of every band this launch will be cut into.
+    uint32_t groups = WORK_SHARDS;
+    {   const uint64_t spp_now = std::max<uint64_t>(1, (uint64_t)s1 - s0), pixels = (uint64_t)sel.rows.size() * st.width;
+        const uint64_t ws = (opt && opt->workspace_bytes) ? opt->workspace_bytes : (32ull << 30);
+        const uint64_t cap = std::max<uint64_t>(1, std::min<uint64_t>(ws / 12, (1ull << 31) - 16 * RUN_LIMIT) / spp_now);
+        const uint64_t band_pixels = std::max<uint64_t>(1, std::min(cap, pixels));                       // (the band plan below arrives at the same figure)
+        groups *= (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (pixels + band_pixels - 1) / band_pixels)); }
+    if (ctx->row_cost.empty() || rng_mode != MI355RT_RNG_CTR) groups = 0;                  // natural order
+    const bool same_rows = ctx->rows_valid && sel.rows == ctx->rows_host && groups == ctx->order_groups;
     if (!same_rows) {
-        if (ctx->have_last) HIP_TRY(hipEventSynchronize(ctx->done));   // a previous call's row-table upload may still read rows_host
+        if (ctx->have_last) HIP_TRY(hipEventSynchronize(ctx->done));   // a previous call's row-table upload may still read tables_host
         ctx->rows_host.swap(sel.rows);
+        static const std::vector<float> no_cost;
+        row_tables(ctx->rows_host, groups ? ctx->row_cost : no_cost, groups, ctx->tables_host);
+        ctx->order_groups = groups;
         ctx->rows_valid = false;
     }
-    const uint32_t rng_mode = opt ? opt->rng_mode : (uint32_t)MI355RT_RNG_CTR;
     const bool fixed_aabb = opt && (opt->flags & MI355RT_FLAG_FIXED_AABB) != 0u;
     if (opt && (opt->flags & ~MI355RT_FLAG_FIXED_AABB) != 0u) return fail(MI355RT_ERR_INVALID, "options.flags has unknown bits");
     if (fixed_aabb && rng_mode != MI355RT_RNG_CTR) return fail(MI355RT_ERR_INVALID, "MI355RT_FLAG_FIXED_AABB needs MI355RT_RNG_CTR (the replay mode reproduces the reference as it is)");
@@ -623,10 +722,13 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
     if (n_rows == 0) return MI355RT_OK;
 
     if (!same_rows) {
-        if ((rc = ctx->rows.ensure(n_rows))) return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->rows.p, ctx->rows_host.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        if ((rc = ctx->rows.ensure(3 * (size_t)n_rows))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->rows.p, ctx->tables_host.data(), 3 * (size_t)n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         ctx->rows_valid = true;
     }
+    const uint32_t* d_rows_natural = ctx->rows.p;
+    const uint32_t* d_rows_processing = ctx->rows.p + n_rows;
+    const uint32_t* d_out_row = ctx->order_groups ? ctx->rows.p + 2 * (size_t)n_rows : nullptr;      // null: processing order == output order
     if ((rc = ctx->stats.ensure(STATS_WORDS))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, STATS_WORDS * sizeof(unsigned long long), stream));
 
@@ -638,7 +740,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             return fail(MI355RT_ERR_INVALID, "progressive rendering needs MI355RT_RNG_CTR (the reference stream of a row is sequential over its pixels)");
         if ((rc = ctx->fold_stack.ensure((size_t)n_rows * std::max(st.max_depth, 1u) * 3))) return rc;
         RefParams rp{};
-        rp.prims = ctx->prims.p; rp.mats = ctx->mats.p; rp.nodes = ctx->nodes.p; rp.tris = ctx->tris.p; rp.rows = ctx->rows.p;
+        rp.prims = ctx->prims.p; rp.mats = ctx->mats.p; rp.nodes = ctx->nodes.p; rp.tris = ctx->tris.p; rp.rows = d_rows_natural;
         rp.sky = ctx->sky_w ? ctx->sky.p : nullptr; rp.sky_w = ctx->sky_w; rp.sky_h = ctx->sky_h; rp.textures = ctx->textures.p;
         rp.out_packed = (uint32_t*)d_out_packed; rp.out_linear = (float*)d_out_linear; rp.fold_stack = ctx->fold_stack.p; rp.stats = ctx->stats.p;
         rp.n_prims = ctx->n_prims; rp.n_mats = ctx->n_mats; rp.n_rows = n_rows;
@@ -662,6 +764,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         uint64_t max_samples = std::min<uint64_t>(ws_cap / 12, (1ull << 31) - 16 * RUN_LIMIT);     // the shard counters overshoot by at most one run per claiming wave's last try; 32-bit headroom
         if (max_samples < spp) return fail(MI355RT_ERR_INVALID, "workspace_bytes too small for one pixel (needs spp * 12 bytes)");
         uint64_t band_pixels_max = std::min<uint64_t>(max_samples / spp, total_pixels);
+        if (d_row_counters) band_pixels_max = st.width;                  // the probe: a band = a row
         // Only what a band needs is allocated.  When even that does not fit (another tenant on the GPU, a small device),
         // halve the band and try again: more, smaller bands give the same image (tiling invariance), just more launches.
         for (;;) {
@@ -677,7 +780,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, (size_t)n_bands * ctr_words * sizeof(uint32_t), stream));
 
         RenderParams p{};
-        p.prims = ctx->prims.p; p.mats = ctx->mats.p; p.nodes = ctx->nodes.p; p.tris = ctx->tris.p; p.rows = ctx->rows.p;
+        p.prims = ctx->prims.p; p.mats = ctx->mats.p; p.nodes = ctx->nodes.p; p.tris = ctx->tris.p; p.rows = d_rows_processing;
         p.sky = ctx->sky_w ? ctx->sky.p : nullptr; p.sky_w = ctx->sky_w; p.sky_h = ctx->sky_h; p.textures = ctx->textures.p;
         p.radiance = ctx->radiance.p; p.stats = ctx->stats.p;
         p.n_prims = ctx->n_prims; p.n_mats = ctx->n_mats;
@@ -695,6 +798,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
         r.spp = (uint32_t)spp; r.inv_spp = 1.0f / (float)s1;                             // renderer.rs:85
         r.accum = (float*)d_accum; r.accum_load = s0 != 0 ? 1u : 0u;
+        r.out_row = d_out_row; r.width = st.width; r.width_mul = p.width_mul; r.width_shift = p.width_shift;
         const uint32_t resident = (uint32_t)(ctx->cu_count * ctx->blocks_per_cu[variant]);
         block_threads = block_threads_of(variant);
         std::vector<float> band_ms;
@@ -703,6 +807,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             const uint64_t np = std::min<uint64_t>(band_pixels_max, total_pixels - p0);
             p.band_pixel0 = (uint32_t)p0; p.band_samples = (uint32_t)(np * spp);
             p.batch_counter = ctx->counters.p + (size_t)b * ctr_words;
+            if (d_row_counters) p.stats = d_row_counters + STATS_WORDS * (size_t)b;   // (a whole counter block per row: diagnostic builds write all of it)
             const bool wf = is_wavefront(variant);
             const uint32_t run_min = wf ? RUN_WAVEFRONT_MIN : BATCH_MIN, run_max = wf ? RUN_WAVEFRONT : BATCH_MAX;   // what the kernel's WorkCursorT is compiled with
             p.shard_samples = (p.band_samples + WORK_SHARDS - 1) / WORK_SHARDS;
@@ -726,9 +831,10 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], stream));
             if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
             if (launch_render_ctr(p, variant, grid, stream) != 0) return fail(MI355RT_ERR_HIP, "k_render_ctr launch failed");
+            ctx->launched_variants |= 1u << variant;
             if (stats) HIP_TRY(hipEventRecord(ctx->ev[1], stream));
             if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
-            if (launch_resolve(r, stream) != 0) return fail(MI355RT_ERR_HIP, "k_resolve launch failed");
+            if (!d_row_counters && launch_resolve(r, stream) != 0) return fail(MI355RT_ERR_HIP, "k_resolve launch failed");
             if (pe2) { HIP_TRY(hipEventRecord(pe2, stream)); ++ctx->timed_launches; }
             if (stats) {
                 HIP_TRY(hipEventRecord(ctx->ev[2], stream));
@@ -748,7 +854,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         unsigned long long h[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(h, ctx->stats.p, sizeof h, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (int erc = report_device_error(ctx)) return erc;          // a wave of THIS render gave up: the image is incomplete
+        if (int erc = report_device_error(ctx, true)) return erc;    // a wave of THIS render gave up: the image is incomplete
         stats->render_kernel_ms = render_ms; stats->resolve_kernel_ms = resolve_ms; stats->total_ms = total_ms;
         stats->samples = h[0]; stats->rays = h[1];
         stats->bands = n_bands; stats->grid_blocks = grid_blocks; stats->block_threads = block_threads;
@@ -788,6 +894,20 @@ int mi355rt_debug_read_counters(mi355rt_context* ctx, unsigned long long* out40)
     if (!ctx || !out40 || !ctx->stats.p) return fail(MI355RT_ERR_INVALID, "no counters");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpy(out40, ctx->stats.p, STATS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MI355RT_OK;
+    });
+}
+
+// Diagnostic hook (not part of the public header): the row tables of the last render on this context -- 3 x n entries (natural, processing,
+// out_row; see row_tables()) -- and the per-image-row cost the processing order was built from (`cost`, `height` entries; may be null).
+int mi355rt_debug_read_row_tables(mi355rt_context* ctx, uint32_t* tables, uint32_t capacity_entries, uint32_t* n_rows, float* cost, uint32_t cost_capacity, uint32_t* n_cost) {
+    return guard([&]() -> int {
+    if (!ctx || !n_rows) return fail(MI355RT_ERR_INVALID, "null");
+    const size_t n = ctx->rows_host.size();
+    *n_rows = (uint32_t)n;
+    if (tables) { if (capacity_entries < 3 * n || ctx->tables_host.size() != 3 * n) return fail(MI355RT_ERR_INVALID, "row tables: capacity"); std::memcpy(tables, ctx->tables_host.data(), 3 * n * sizeof(uint32_t)); }
+    if (n_cost) *n_cost = (uint32_t)ctx->row_cost.size();
+    if (cost) { if (cost_capacity < ctx->row_cost.size()) return fail(MI355RT_ERR_INVALID, "row cost: capacity"); std::memcpy(cost, ctx->row_cost.data(), ctx->row_cost.size() * sizeof(float)); }
     return MI355RT_OK;
     });
 }

@@ -14,7 +14,8 @@
 //                             LDS_NODE_CAP nodes (the top levels) are what k_render_ctr_sm keeps in LDS
 //   DevTri[n_tris]      48 B  triangles re-ordered into leaf order, stored as v0, e1=v1-v0, e2=v2-v0,
 //                             normal (the same f32 subtractions bvh.rs:95-96 performs per test)
-//   rows[n_rows]         4 B  local output row -> absolute image row y (the RNG key)
+//   rows[3 * n_rows]     4 B  three tables: local output row -> absolute image row y; PROCESSING row -> absolute y (the RNG key; what the
+//                             counter-mode kernels read); processing row -> local output row (what the resolve kernel reads)
 //   sky[h*w*3]           4 B  optional equirect HDR skybox, per-lane nearest-texel gather on miss
 //   radiance[band]      12 B  three floats per path (sample-major inside a pixel), written once by
 //                             the path tracer and read once by the resolve kernel
@@ -90,14 +91,15 @@ constexpr uint32_t WAVE_TIME_WORDS = 6;        // diagnostic builds: per wave {s
 
 struct RenderParams {
     const DevPrim* prims; const DevMat* mats; const DevNode* nodes; const DevTri* tris;
-    const uint32_t* rows;        // local row -> absolute y
+    const uint32_t* rows;        // processing row (the band's pixels are numbered in processing order) -> absolute y
     const float* sky; uint32_t sky_w, sky_h;   // equirect HDR skybox (RGB f32), null = constant miss colour
     const DevTexture* textures;  // images of the MI355RT_MAT_TEXTURE materials (indices validated at upload)
     float* radiance;             // 3 floats per band sample
     uint32_t* batch_counter;     // WORK_SHARDS counters (WORK_SHARD_STRIDE words apart): next unclaimed sample of each shard; zeroed per band
     unsigned long long* stats;   // [0] = paths started, [1] = rays traced
-    unsigned long long* err;     // sticky per-context failure count: a wave that gave up a bounded wait adds 1 (never reset by a render;
-                                 // the host compares it with what it has already reported -- rt_api.cpp, check_device_error)
+    unsigned long long* err;     // sticky per-context failure word (never reset by a render; the host compares it with what it has already
+                                 // reported -- rt_api.cpp, report_device_error): bits 0..31 count the waves that gave up a bounded wait,
+                                 // bits 32..39 collect WHICH waits (WAIT_*); the host adds which kernel it had launched
     unsigned long long* wave_times;  // diagnostic builds only: WAVE_TIME_WORDS u64 per wave; null otherwise
     uint32_t n_prims, n_mats;
     float miss[3];
@@ -120,6 +122,10 @@ struct RenderParams {
     uint32_t spin_limit_idle;    // wavefront / pool kernels: polls without progress before a wave gives up (SPIN_LIMIT_IDLE; a diagnostic hook lowers it)
     uint32_t spin_limit_entry;   // wavefront kernel: polls of one ring entry before a lane gives up (SPIN_LIMIT_ENTRY)
 };
+// The bounded waits a kernel can give up (RenderParams.err): an idle wave of the wavefront kernel that saw no progress in its workgroup; a lane
+// whose ring entry was never written (pop) or never emptied (push); a wave that left because another wave of its workgroup had given up;
+// (reference build) a producer of the walk pool whose walk results did not come back; a walker of the pool that saw neither requests nor progress.
+enum : uint32_t { WAIT_WF_IDLE = 1u, WAIT_WF_RING = 2u, WAIT_WF_FOLLOWED = 4u, WAIT_POOL_RESULTS = 8u, WAIT_POOL_WALKER_IDLE = 16u };
 constexpr uint32_t SPIN_LIMIT_IDLE = 1u << 22;    // watchdog bounds: seconds of polling, never reached by a healthy launch
 constexpr uint32_t SPIN_LIMIT_ENTRY = 1u << 20;
 
@@ -162,6 +168,8 @@ struct ResolveParams {
     uint32_t accum_load;         // 1: start from accum[] (samples before this launch), 0: start from zero
     uint32_t band_pixel0, band_pixels, spp;
     float inv_spp;               // 1 / (samples accumulated so far including this launch)
+    const uint32_t* out_row;     // processing row -> local output row (rt_api.cpp row_tables()); null: the band's pixels are in output order
+    uint32_t width, width_mul, width_shift;   // image width and its magic pair (pixel -> processing row)
 };
 
 struct RefParams {               // MI355RT_RNG_REF: one lane per selected row

@@ -444,7 +444,11 @@ __global__ void __launch_bounds__(256) k_resolve(const ResolveParams P) {
     const uint32_t s = lane & 15u;
     const uint32_t p = wave * 4u + (lane >> 4);                  // this row's pixel within the band
     const bool valid = p < P.band_pixels;
-    const size_t o = (size_t)P.band_pixel0 + p;
+    size_t o = (size_t)P.band_pixel0 + p;                        // the pixel's number in processing order ...
+    if (P.out_row && valid) {                                    // ... and where it belongs in the output (rows are processed dearest first, rt_api.cpp)
+        const uint32_t jp = fastdiv((uint32_t)o, P.width_mul, P.width_shift);
+        o = (size_t)P.out_row[jp] * P.width + ((uint32_t)o - jp * P.width);
+    }
     const float* __restrict__ rad = P.radiance + 3u * (size_t)(valid ? p : 0u) * P.spp;     // 3 floats per sample
     float4* __restrict__ accum = reinterpret_cast<float4*>(P.accum);
     f3 acc = mk(0.f, 0.f, 0.f);                                  // meaningful in lane 0 of the row

@@ -238,7 +238,12 @@ DI void render_ctr_pool(const RenderParams& P) {
             m[w].ro = mk(0, 0, 0); m[w].rd = mk(0, 0, 1); m[w].ix = m[w].iy = m[w].iz = 0.f; m[w].len_raw = 0.f; m[w].node = NODE_END; m[w].best_t = 0.f;
             m[w].best_tri = 0xFFFFFFFFu; m[w].leaf_a = m[w].leaf_b = 0; has[w] = false; ticket[w] = POOL_EMPTY; slot[w] = 0;
         }
-        uint32_t spins = 0;
+        uint32_t spins = 0, seen_progress = 0;
+        // The watchdogs of this kernel count polls without PROGRESS in the workgroup, as the wavefront kernel's does (rt_wavefront.h): the sum of the
+        // ring counters ([0] requests published, [1] tickets drawn), [4] producer passes run and [5] results handed back moves whenever any wave
+        // of the workgroup gets something done; a wave that sees it move starts counting again.
+        auto progress = [&]() { return __hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + __hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) +
+                                         __hip_atomic_load(&ctrl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + __hip_atomic_load(&ctrl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
         for (;;) {
             // refill: a walk slot with neither a walk nor a ticket draws the next ticket (one ds_add per wave for all of them);
             // a ticketed slot takes its request once the ring entry is filled
@@ -289,6 +294,7 @@ DI void render_ctr_pool(const RenderParams& P) {
                         results[2u * slot[w]] = __float_as_uint(m[w].best_t); results[2u * slot[w] + 1u] = m[w].best_tri;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __hip_atomic_store(&flags[slot[w]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        atomicAdd(&ctrl[5], 1u);
                         has[w] = false;
                     }
                 }
@@ -296,10 +302,14 @@ DI void render_ctr_pool(const RenderParams& P) {
                 if (__hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;     // no producer left: nothing can be outstanding
                 if (__hip_atomic_load(&ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > P.spin_limit_idle) { if (lane == 0) atomicOr(&ctrl[3], 1u); break; }
+                { const uint32_t pr = progress(); if (pr != seen_progress) { seen_progress = pr; spins = 0; } }
+                if (++spins > P.spin_limit_idle) { if (lane == 0) atomicOr(&ctrl[3], (uint32_t)WAIT_POOL_WALKER_IDLE); break; }
             }
         }
-        if (lane == 0 && P.err && __hip_atomic_load(&ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) atomicAdd(P.err, 1ull);
+        if (lane == 0 && P.err) {
+            const uint32_t waits = __hip_atomic_load(&ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (waits != 0u) { atomicAdd(P.err, 1ull); atomicOr(P.err, (unsigned long long)waits << 32); }
+        }
         return;
     }
 
@@ -308,7 +318,7 @@ DI void render_ctr_pool(const RenderParams& P) {
     WorkCursor wc; wc.init();
     PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
     ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
-    uint32_t state = ST_IDLE, cursor = 0, spins = 0;
+    uint32_t state = ST_IDLE, cursor = 0, spins = 0, stall = 0, seen_progress = 0;
     bool walk_done = false;
     Cand best; cand_reset(best);
     float len_raw = 0.f, res_t = 0.f; uint32_t res_tri = 0xFFFFFFFFu;        // what mesh_accept needs of the walk once it is back
@@ -334,10 +344,16 @@ DI void render_ctr_pool(const RenderParams& P) {
         if (nW != 0u && nP + nS + nI < min_ready) {
             if (__hip_atomic_load(&ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > P.spin_limit_idle) { if (lane == 0) atomicOr(&ctrl[3], 1u); failed = true; break; }
+            {   // (progress anywhere in the workgroup -- a request taken, a result handed back, a pass run -- restarts the count; see the walkers)
+                const uint32_t pr = __hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + __hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) +
+                                    __hip_atomic_load(&ctrl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + __hip_atomic_load(&ctrl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pr != seen_progress) { seen_progress = pr; stall = 0; } }
+            ++spins;
+            if (++stall > P.spin_limit_idle) { if (lane == 0) atomicOr(&ctrl[3], (uint32_t)WAIT_POOL_RESULTS); failed = true; break; }
             if (spins < P.pool_patience || nP + nS + nI == 0u) continue;         // waited long enough: run what is there
         }
         spins = 0;
+        if (lane == 0) atomicAdd(&ctrl[4], 1u);                                    // a pass is about to run: progress
 
         if (nP != 0u && nP >= nS + nI) {
             // ---- TOP: hittable.rs:45-58 from each lane's cursor ----
@@ -414,7 +430,7 @@ DI void render_ctr_pool(const RenderParams& P) {
     if (lane == 0 && P.stats) {
         atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr);
     }
-    if (lane == 0 && P.err && failed) atomicAdd(P.err, 1ull);
+    if (lane == 0 && P.err && failed) { atomicAdd(P.err, 1ull); atomicOr(P.err, (unsigned long long)__hip_atomic_load(&ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << 32); }
 }
 __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_pool(const RenderParams P) { render_ctr_pool<false>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_SM) MI355RT_OCC_SMK k_render_ctr_pool_fixaabb(const RenderParams P) { render_ctr_pool<true>(P); }

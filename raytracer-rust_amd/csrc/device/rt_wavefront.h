@@ -41,6 +41,12 @@
 #ifndef MI355RT_WF_WALK_MIN_ACTIVE
 #define MI355RT_WF_WALK_MIN_ACTIVE 0                        // a WALK pass ends at a round boundary once fewer than this many of its walks are unfinished (0: runs its rounds)
 #endif
+#ifndef MI355RT_WF_REGEN_PENALTY
+#define MI355RT_WF_REGEN_PENALTY 0
+#endif
+#ifndef MI355RT_WF_DRAIN_ROUNDS
+#define MI355RT_WF_DRAIN_ROUNDS 0                           // rounds of a WALK pass once the wave's work cursor is exhausted (0: as always)
+#endif
 #ifndef MI355RT_WF_UNIFORM_WALK
 #define MI355RT_WF_UNIFORM_WALK 0                           // WALK reads the mesh record through scalar loads when every slot of the pass is in the same mesh
 #endif
@@ -429,7 +435,13 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #endif
             constexpr uint32_t T0 = MI355RT_WF_T0PRICE;                  // a SHADE pass goes on with the head of the list for the rays it generates
             consider(WQ_SHADE + 3u, cS3, 5u + T0); consider(WQ_SHADE + 2u, cS2, 10u + T0); consider(WQ_SHADE + 1u, cS1, 8u + T0);
+#if MI355RT_WF_REGEN_PENALTY > 0
+            // A/B (round 4): starting new paths is charged a fixed waste, so that a reasonably filled pass over OLD paths goes first and long paths
+            // do not sit in thin queues until the work cursor runs dry.
+            if (cS0 + cF != 0u) { const uint32_t w = (5u + T0) * (64u - min(cS0 + cF, 64u)) + (cF != 0u ? (uint32_t)MI355RT_WF_REGEN_PENALTY : 0u); if (w <= waste) { waste = w; stage = WQ_SHADE; best = cS0 + cF; } }
+#else
             consider(WQ_SHADE, cS0 + cF, 5u + T0);                      // terminal class: free slots ride along (both only regenerate)
+#endif
         }
         if (stage == WQ_NONE) {
             if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
@@ -590,7 +602,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             // only extra work.  (Two queued leaves per lane with a leaf phase per queue slot were measured too: the second slot's
             // phases run nearly empty and cost more than the stalls they avoid -- +3 % / +7 %.)
             uint32_t resume = NODE_END; bool stalled = false;
-            for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
+            const int max_rounds = (MI355RT_WF_DRAIN_ROUNDS > MI355RT_WF_ROUNDS && wc.exhausted()) ? MI355RT_WF_DRAIN_ROUNDS : MI355RT_WF_ROUNDS;
+            for (int round = 0; round < max_rounds; ++round) {
                 const uint64_t walking = __ballot(have && (m.leaf_b != 0u || m.node != NODE_END));
                 if (walking == 0ull) break;
 #if MI355RT_WF_WALK_MIN_ACTIVE > 0
@@ -678,7 +691,15 @@ DI void render_ctr_wavefront(const RenderParams& P) {
     }
     // A wave that gave up a bounded wait left paths unfinished: count it in the context's sticky error word, which the host reads
     // back behind every render (rt_api.cpp) -- the call that sees it returns MI355RT_ERR_HIP, whether or not it asked for stats.
-    if (__ballot(failed) != 0ull && lane == 0 && P.err) atomicAdd(P.err, 1ull);
+    // The word also says WHICH wait, so that one failure in a log explains itself -- worked out here, behind the loop, from what the wave still
+    // holds (anything in the loop itself costs the kernel 2 %, measured): a wave whose idle count ran out gave up for lack of progress; a wave
+    // with a lane that failed on a ring entry gave up there; the rest only followed the workgroup's error flag out.
+    const uint64_t failed_lanes = __ballot(failed);
+    if (failed_lanes != 0ull && lane == 0 && P.err) {
+        const uint32_t wait = spins > P.spin_limit_idle ? (uint32_t)WAIT_WF_IDLE : failed_lanes != ~0ull ? (uint32_t)WAIT_WF_RING : (uint32_t)WAIT_WF_FOLLOWED;
+        atomicAdd(P.err, 1ull);
+        atomicOr(P.err, (unsigned long long)wait << 32);
+    }
 }
 #ifndef MI355RT_OCC_WF
 #define MI355RT_OCC_WF 6

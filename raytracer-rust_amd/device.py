@@ -94,7 +94,7 @@ def _check(rc, what, library=None):
 
 def set_knob(name, value, library=None):
     """Diagnostic: process-wide default knob for every context created afterwards (also inside the one-shot calls).
-    Knobs: kernel, guided_mult, spin_idle, spin_entry, wave_times, inline_steps, trav_min, walkers, pool_patience (rt_api.cpp)."""
+    Knobs: kernel, guided_mult, spin_idle, spin_entry, wave_times, row_order, inline_steps, trav_min, walkers, pool_patience (rt_api.cpp)."""
     L = library or lib()
     _check(L.mi355rt_debug_set_knob(None, name.encode(), int(value)), f"mi355rt_debug_set_knob({name})", L)
 
@@ -230,6 +230,18 @@ class Context:
         v = C.c_uint32()
         _check(self._L.mi355rt_debug_kernel_variant(self._h, C.byref(v)), "mi355rt_debug_kernel_variant", self._L)
         return v.value
+
+    def row_tables(self):
+        """Diagnostic: (natural, processing, out_row) row tables of the last render on this context and the per-image-row cost (rays per path
+        of set_scene's probe; empty when the rows are processed in image order)."""
+        n, nc = C.c_uint32(), C.c_uint32()
+        f = self._L.mi355rt_debug_read_row_tables
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        _check(f(self._h, None, 0, C.byref(n), None, 0, C.byref(nc)), "mi355rt_debug_read_row_tables", self._L)
+        t = np.zeros(3 * n.value, np.uint32); cost = np.zeros(nc.value, np.float32)
+        _check(f(self._h, t.ctypes.data, t.size, C.byref(n), cost.ctypes.data, cost.size, C.byref(nc)), "mi355rt_debug_read_row_tables", self._L)
+        return t[:n.value], t[n.value:2 * n.value], t[2 * n.value:], cost
 
     def set_timing(self, enable=True):
         _check(self._L.mi355rt_context_set_timing(self._h, 1 if enable else 0), "mi355rt_context_set_timing", self._L)

@@ -140,9 +140,10 @@ def test_mesh_kernels_equal_the_lockstep_walk(name, native, oracle_mod, abi, kno
         try:
             gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(), library=library)
         except device.RenderError as e:
-            # A kernel of the reference build reported its watchdog once in round 3's ~150 renders of this loop (which of the eight
-            # configurations was not recorded then; it is now) -- a clean MI355RT_ERR_HIP, never a wrong image.  It is a bit-identity reference, not a product kernel: one retry, and the
-            # case is named if it fails again.  A product-library kernel gets no second chance.
+            # A kernel of the reference build reported its watchdog once in round 3 (5 waves = the 4 walkers + 1 producer of a 4-walker
+            # walk pool; cause not found by inspection of the ring protocol) -- a clean MI355RT_ERR_HIP, never a wrong image.
+            # Since round 4 the pool's watchdogs count polls without PROGRESS and the message names kernel and wait.  It is a bit-identity
+            # reference, not a product kernel: one retry, the full message in the warning.  A product-library kernel gets no second chance.
             if library is None or "watchdog" not in str(e):
                 raise
             import warnings

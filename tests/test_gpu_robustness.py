@@ -96,6 +96,10 @@ def test_a_wave_that_gives_up_is_reported_on_the_asynchronous_path(native, abi):
     with pytest.raises(device.RenderError, match="watchdog") as e:
         ctx.check()
     assert e.value.rc == abi.ERR_HIP
+    # the message explains itself: which kernel, which of its bounded waits gave up, under which limits, and that it was an EARLIER render
+    msg = str(e.value)
+    assert "in an earlier render on this context" in msg and "k_render_ctr_wf" in msg and f"(variant {ctx.kernel_variant()})" in msg
+    assert "idle: no progress in the workgroup" in msg and "limits: 1 idle polls" in msg
     ctx.check()                                                        # reported once
     # (2) ... the next render on the context reports the previous one
     ctx.render(out.data_ptr(), None, abi.Options.make(), None)
@@ -110,9 +114,19 @@ def test_a_wave_that_gives_up_is_reported_on_the_asynchronous_path(native, abi):
         ctx.read_timing()
     ctx.set_timing(False)
     # (4) ... and the synchronous form reports its own render
-    with pytest.raises(device.RenderError, match="watchdog"):
+    with pytest.raises(device.RenderError, match="watchdog") as e4:
         ctx.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
+    assert "in this render" in str(e4.value) and "earlier" not in str(e4.value)
     ctx.close()
+    # the reference build's walk pool names its own waits (a producer whose results did not come back / a walker without requests)
+    R = device.refs()
+    pool = device.Context(0, library=R)
+    pool.set_knob("kernel", 5); pool.set_knob("spin_idle", 1)
+    pool.set_scene(sc, sc.camera, sc.settings)
+    with pytest.raises(device.RenderError, match="watchdog") as e5:
+        pool.render(out.data_ptr(), None, abi.Options.make(), None, want_stats=True)
+    assert "k_render_ctr_pool (variant 5)" in str(e5.value) and "pool " in str(e5.value)
+    pool.close()
     # the one-shot call (what src/main.rs:57 would bind) is synchronous: same error code, no image handed over as OK
     device.set_knob("spin_idle", 1)
     try:

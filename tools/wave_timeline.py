@@ -11,7 +11,9 @@ SCENES = {"cornell": ("data/scenes/tungsten/cornell-box/scene.json", 30, False),
           "teapot": ("data/scenes/tungsten/teapot/scene.json", 64, True)}
 path, depth, skip = SCENES[sys.argv[1] if len(sys.argv) > 1 else "cornell"]
 sc = host.LoadedScene(os.path.join(ROOT, path), 800, 600, 256, depth, skip_unknown_primitives=skip)
-ctx = device.Context(0); ctx.set_knob("wave_times", 1); ctx.set_scene(sc, sc.camera, sc.settings)
+ctx = device.Context(0); ctx.set_knob("wave_times", 1)
+if os.environ.get("ROW_ORDER"): ctx.set_knob("row_order", int(os.environ["ROW_ORDER"]))
+ctx.set_scene(sc, sc.camera, sc.settings)
 out = torch.zeros(800 * 600, dtype=torch.int32, device="cuda")
 for parts in (1, 8):
     opt = abi.Options.make(strip_rows=5, n_parts=parts, part=0)
@@ -21,6 +23,10 @@ for parts in (1, 8):
     assert device.lib().mi355rt_debug_read_wave_times(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 16384, C.byref(n)) == 0
     w = buf[:6 * n.value].reshape(-1, 6).astype(np.float64)
     t0 = w[:, 0].min(); start = (w[:, 0] - t0) / 100.0; end = (w[:, 1] - t0) / 100.0     # microseconds (100 MHz)
+    if parts == 1:
+        nat, proc, outr, cost = ctx.row_tables()
+        print("   row cost (rays per path) by image row, every 25th:", " ".join(f"{c:.2f}" for c in cost[::25]) if len(cost) else "none (image order)")
+        print("   processing order, first 12 rows of shard 0:", list(proc[:12]), "... last 6 of shard 0:", list(proc[len(proc) // 8 - 6:len(proc) // 8]))
     print(f"parts={parts}: kernel {st.render_kernel_ms:.3f} ms, waves {n.value}, paths/wave mean {w[:,2].mean():.0f} min {w[:,2].min():.0f} max {w[:,2].max():.0f}")
     print("   wave start  us: p50 %.0f p99 %.0f max %.0f" % tuple(np.percentile(start, [50, 99, 100])))
     print("   wave end    us: p1 %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(end, [1, 10, 50, 90, 99, 100])))
