@@ -13,7 +13,9 @@
  * arrays, and the caller owns every buffer it passes in.
  *
  * Conventions
- *   - return value 0 = OK, negative = error; nothing aborts, nothing throws across the ABI;
+ *   - return value 0 = OK, negative = error; nothing aborts, nothing throws across the ABI (every
+ *     entry point of both libraries runs inside an exception barrier: a failed host allocation is
+ *     MI355RT_ERR_OOM, any other C++ exception MI355RT_ERR_HIP / _IO with its text);
  *     mi355rt_last_error() returns a thread-local message for the last failure.
  *   - output layout == render_scene's Vec<u32>: width*height, row-major, row 0 = top,
  *     0x00RRGGBB (src/color.rs:87-93).
@@ -32,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 2u   /* 2: mi355rt_scene.textures, MI355RT_MAT_TEXTURE */
+#define MI355RT_ABI_VERSION 3u   /* 2: mi355rt_scene.textures, MI355RT_MAT_TEXTURE; 3: mi355rt_context_check exported, quads must carry a (near-)unit normal */
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MI355RT_OK               0
@@ -213,6 +215,12 @@ typedef struct mi355rt_context mi355rt_context;
 
 int  mi355rt_context_create(int hip_device, mi355rt_context** out_ctx);
 void mi355rt_context_destroy(mi355rt_context* ctx);
+/* Uploads the scene (every array is copied: the caller's buffers may be freed afterwards) and picks the kernel for it.  BLOCKING, and it may
+ * LAUNCH: for mesh-free scenes that mix a rough conductor with another scattering material a probe render of the same view (<= 64 pixels across,
+ * <= 4 samples per pixel; deterministic, a fraction of a millisecond) runs on the NULL stream and is waited for -- its rays per path decide
+ * between the lockstep and the wavefront kernel.  The probe stays out of the timing pool (mi355rt_context_set_timing).  Like every entry point
+ * that looks at the context's error word, set_scene returns a pending watchdog failure of an EARLIER asynchronous render on this context
+ * (MI355RT_ERR_HIP, once) instead of proceeding; call it again.                                                                          */
 int  mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene,
                                const mi355rt_camera* camera, const mi355rt_settings* settings);
 /* Number of rows the given options select (so callers can size their buffers).                  */

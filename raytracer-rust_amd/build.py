@@ -46,11 +46,12 @@ def _host_deps():
 
 
 def kernel_hash():
-    """sha256 over everything that decides the device code: the kernel source, every header of csrc/device and the
-    hipcc flags.  profiles/pmc_counters.json records it, and bench.py refuses counters taken on another kernel."""
+    """sha256 over everything that decides the device code AND how it is launched: the kernel source, every header of csrc/device, the
+    host half (rt_api.cpp: grid size, shard size, guided_div, the choice of the kernel variant) and the hipcc flags.
+    profiles/pmc_counters.json records it, and bench.py refuses counters taken on another library."""
     import hashlib
     h = hashlib.sha256()
-    for f in DEVICE_SRCS[:1] + DEVICE_HEADERS:              # rt_kernels.hip and every header it includes (rt_device.h, rt_math.h, ...)
+    for f in DEVICE_SRCS + DEVICE_HEADERS:                  # rt_kernels.hip, rt_api.cpp and every header they include (rt_device.h, rt_math.h, ...)
         h.update(open(f, "rb").read())
     h.update(" ".join(HIPCC_FLAGS).encode())
     return h.hexdigest()[:16]

@@ -408,6 +408,14 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         // below EPSILON (vec3.rs:120-122) the first time the sphere is hit.  Refused here rather than rendered.
         if (p.kind == MI355RT_PRIM_SPHERE && std::fabs(p.data[3]) < 1e-4f)
             return fail(MI355RT_ERR_INVALID, "sphere radius |r| < 1e-4: the reference panics on it (Vec3 / f32, vec3.rs:120-122 via sphere.rs:38)");
+        // The quad test divides by dot(normal, direction) with the short division of rt_math.h (div_bounded), proven equal to `/` for divisors of
+        // magnitude <= 2^25.  The reference's constructor always stores a unit normal (quad.rs:26-79, n = normalize(e0 x e1)), so |divisor| <= ~1;
+        // a caller that hands in a scaled normal would leave the proven range while the reference semantics (IEEE division) go on: refused.
+        if (p.kind == MI355RT_PRIM_QUAD) {
+            bool ok = true;
+            for (int k = 9; k < 12; ++k) ok = ok && std::fabs(p.data[k]) <= 0x1p20f;                       // (false for NaN and infinities too)
+            if (!ok) return fail(MI355RT_ERR_INVALID, "quad normal (data[9..11]) is not finite or larger than 2^20: the reference stores a unit normal (quad.rs:26-79)");
+        }
         if (p.kind == MI355RT_PRIM_CUBE || p.kind == MI355RT_PRIM_MESH) {
             const float* o2w = p.data; const float* w2o = p.data + 16;
             std::memcpy(d.d, w2o, 64);

@@ -79,7 +79,8 @@ DI bool hit_plane(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
 // tungsten/objects/quad.rs:83-132.  The two cheap rejections (parallel ray, t out of range) are folded into one
 // predicate so the wave takes a single branch into the parallelogram test; the arithmetic is unchanged (the
 // division also runs for |denom| < EPS lanes, whose result is discarded).
-// FASTD: t by div_bounded() (rt_math.h).  t is used only where |denom| >= EPS, and |denom| <= |n||d| ~ 1, so the divisor is in range; a
+// FASTD: t by div_bounded() (rt_math.h).  t is used only where |denom| >= EPS, and |denom| <= |n||d| ~ 1 (the host refuses quads whose normal
+// is not of unit scale: rt_api.cpp build_device_scene), so the divisor is in range; a
 // numerator below 2^-100 gives a |t| below 2^-86 either way (rejected: t <= t_min), one of 2^100 or more sends the whole wave to the
 // compiler's division (ballot); infinities and NaN come out of v_div_fixup_f32 as they do there.
 template <bool FASTD = false>

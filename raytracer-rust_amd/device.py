@@ -129,9 +129,10 @@ def render_multi(scene, camera, settings, devices, options=None, want_linear=Tru
     linear = np.zeros((rows, settings.width, 3), np.float32) if want_linear else None
     stats = abi.Stats()
     devs = (C.c_int * len(devices))(*devices)
-    _check((library or lib()).mi355rt_render_multi(C.byref(sc), C.byref(camera), C.byref(settings), C.byref(options) if options is not None else None,
-                                      devs, len(devices), packed.ctypes.data, linear.ctypes.data if want_linear else None, C.byref(stats)),
-           "mi355rt_render_multi")
+    L = library or lib()
+    _check(L.mi355rt_render_multi(C.byref(sc), C.byref(camera), C.byref(settings), C.byref(options) if options is not None else None,
+                                  devs, len(devices), packed.ctypes.data, linear.ctypes.data if want_linear else None, C.byref(stats)),
+           "mi355rt_render_multi", L)
     return packed, linear, stats
 
 

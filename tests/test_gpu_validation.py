@@ -104,3 +104,19 @@ def test_context_reuse_and_scene_switch(native, oracle_mod, abi):
             assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), d, n, 2) == 0
             assert np.array_equal(out, want)
     ctx.close(); hip.hipFree(d)
+
+
+def test_a_scaled_quad_normal_is_refused(native, oracle_mod, abi):
+    """The quad test divides by dot(normal, direction) with a division proven equal to `/` for divisors up to 2^25 (rt_math.h div_bounded); the
+    reference's constructor stores a UNIT normal (tungsten/objects/quad.rs:26-79).  A caller that hands the C ABI a scaled or non-finite normal
+    is outside both: refused at upload, never rendered with arithmetic that could differ from the reference's."""
+    host, device = native
+    sc = load_for_both("cornell", oracle_mod, host, width=16, height=12, spp=1, max_depth=3)
+    quad = next(sc.c.primitives[i] for i in range(sc.c.n_primitives) if sc.c.primitives[i].kind == abi.PRIM_QUAD)
+    old = quad.data[10]
+    for bad in (3.0e7, float("inf"), float("nan")):
+        quad.data[10] = bad
+        rc, msg = _render_rc(device, abi, sc, sc.camera, sc.settings)
+        assert rc == abi.ERR_INVALID and "quad normal" in msg, (bad, rc, msg)
+    quad.data[10] = old
+    assert _render_rc(device, abi, sc, sc.camera, sc.settings)[0] == 0
