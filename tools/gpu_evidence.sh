@@ -21,4 +21,11 @@ find "$OUT/stats_teapot" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stat
 python3 tools/ab_fuzz_scene.py 31 32 33 > "$OUT/ab_fuzz_scene.txt" 2>&1 || { tail -5 "$OUT/ab_fuzz_scene.txt"; exit 1; }
 python3 tools/stamps.py > "$OUT/stamps.txt" 2>&1 || { tail -5 "$OUT/stamps.txt"; exit 1; }
 python3 bench.py --workload cornell-box-400x300x16-d4 --steps 50 --warmup 5 > "$OUT/bench_cornell-box-400x300x16-d4.json" 2> "$OUT/bench_cfg1.err" || { cat "$OUT/bench_cfg1.err"; exit 1; }
+# `python bench.py --gpus N` as typed: the self-launch (one RCCL rank; two rehearsal ranks on this one GPU over gloo) and the one-process fallback form
+MI355RT_BENCH_FORCE_DIST=1 python3 bench.py --gpus 1 --cpu-seconds 0 > "$OUT/bench_selflaunch_rccl_1rank.json" 2> "$OUT/selflaunch1.err" || { cat "$OUT/selflaunch1.err"; exit 1; }
+MI355RT_BENCH_REHEARSE=1 python3 bench.py --gpus 2 --cpu-seconds 0 > "$OUT/bench_selflaunch_rehearsal_2ranks.json" 2> "$OUT/selflaunch2.err" || { cat "$OUT/selflaunch2.err"; exit 1; }
+MI355RT_BENCH_REHEARSE=1 python3 bench.py --gpus 2 --single-process --cpu-seconds 0 > "$OUT/bench_single_process_rehearsal_2parts.json" 2> "$OUT/single2.err" || { cat "$OUT/single2.err"; exit 1; }
+# where the render kernel's WRITE_SIZE comes from: 32-byte vs 64-byte write requests of the L2 (headline workload only)
+python3 tools/pmc_collect.py --out "$OUT/pmc_writes" --workloads cornell-box-800x600x256-d30 --groups '[["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"]]' > "$OUT/pmc_writes.log" 2>&1 || tail -3 "$OUT/pmc_writes.log"
+python3 tools/isa_stats.py > "$OUT/isa_stats.txt" 2>&1
 cat "$OUT/bench_cornell-box-800x600x256-d30.json"
