@@ -1,0 +1,37 @@
+"""The kernels' register and code budgets, read from the built gfx950 code object (no GPU needed: hipcc cross-compiles, tools/isa_stats.py reads the
+ELF notes and the disassembly).  Round 4 measured how little it takes to move these kernels: one more spilled register in the wavefront kernel's loop
+was +2 %, 48 -> 60 KB of code +1.5 % (two CUs share a 64 KB instruction cache).  This test pins what the shipped library was measured with, so that a
+change of the sources that silently costs registers or code shows up before it costs a GPU run.  (Budgets, not equalities: a compiler update may move
+them a little; DESIGN.md 4.1 / 4.1d quote the exact figures of the measured build.)"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# kernel: (VGPRs allowed, spilled VGPRs, code bytes, scratch_ instructions in the ISA)
+BUDGET = {
+    "k_render_ctr_simple": (72, 4, 11 * 1024, 3),           # headline kernel: 7 waves per SIMD
+    "k_render_ctr_nospec": (72, 7, 21 * 1024, 5),
+    "k_render_ctr_nomesh": (80, 5, 23 * 1024, 4),
+    "k_render_ctr_wf_nometal": (80, 8, 50 * 1024, 6),       # teapot, semesterbild: 6 waves per SIMD, 2 workgroups of 12 waves per CU
+    "k_render_ctr_wf": (80, 12, 51 * 1024, 15),
+    "k_render_ctr_wf_meshfree": (64, 16, 25 * 1024, 22),    # veach-mis: 8 waves per SIMD
+    "k_resolve": (16, 0, 2 * 1024, 0),
+}
+
+
+def test_shipped_kernels_stay_inside_their_measured_budgets(native):
+    isa_stats = importlib.import_module("isa_stats")
+    build = importlib.import_module("raytracer-rust_amd.build")
+    stats = {isa_stats.short(k): v for k, v in isa_stats.kernel_stats(build.DEVICE_SO).items()}
+    assert not {"k_render_ctr_sm", "k_render_ctr_pool"} & set(stats)            # the retired mesh kernels are not in the product library
+    for name, (vgprs, spilled, code, scratch) in BUDGET.items():
+        st = stats[name]
+        assert st["vgpr_count"] <= vgprs, (name, st)
+        assert st["vgpr_spill_count"] <= spilled, (name, st)
+        assert st["code_bytes"] <= code, (name, st)
+        assert st.get("scratch_insts", 0) <= scratch, (name, st)
+    wf = stats["k_render_ctr_wf_nometal"]
+    assert wf["group_segment_fixed_size"] <= 163840 // 2                            # two workgroups per CU share the 160 KB of LDS
