@@ -327,10 +327,9 @@ DI bool hit_mesh(cprim_t pr, uint32_t i, const DevNode* __restrict__ nodes, cons
 
 // The HitRecord of the list's winner (hittable.rs:10-27), once per ray.  Lanes of a wave may have different winners, so
 // the primitive record is read per lane here (global loads; L1/L2 resident).
-// finish_hit_at(): the record from the winner's primitive record `pr` -- a per-lane global pointer (finish_hit) or, where the caller knows
-// the winner to be the same for all its active lanes, the wave-uniform constant-address-space pointer (scalar loads, a scalar branch on the kind).
-template <bool HAS_MESH, bool SHARED_TAIL = !HAS_MESH, bool CARRY_Q0 = false, class PrimPtr, class C>
-DI void finish_hit_at(PrimPtr pr, const DevTri* __restrict__ tris, const C& c, f3 ro, f3 rd, Hit& h) {
+template <bool HAS_MESH, bool SHARED_TAIL = !HAS_MESH, bool CARRY_Q0 = false, class C>
+DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__ tris, const C& c, f3 ro, f3 rd, Hit& h) {
+    const DevPrim* __restrict__ pr = prims + c.idx;
     const uint32_t kind = pr->kind;
     if constexpr (CARRY_Q0) h.q0 = *reinterpret_cast<const float4*>(pr->mat0);
     // Mesh-free lists: each kind only says where the hit is and which way its surface faces; HitRecord::set_face_normal
@@ -371,12 +370,6 @@ DI void finish_hit_at(PrimPtr pr, const DevTri* __restrict__ tris, const C& c, f
             set_face(h, rd, outward, pr->material);
         }
     }
-}
-
-template <bool HAS_MESH, bool SHARED_TAIL = !HAS_MESH, bool CARRY_Q0 = false, class C>
-DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__ tris, const C& c, f3 ro, f3 rd, Hit& h) {
-    const DevPrim* __restrict__ pr = prims + c.idx;
-    finish_hit_at<HAS_MESH, SHARED_TAIL, CARRY_Q0>(pr, tris, c, ro, rd, h);
 }
 
 DI uint32_t prim_material_kind(const RenderParams& P, uint32_t idx) { return __float_as_uint(P.prims[idx].mat0[0]); }   // one read, not two dependent ones

@@ -193,11 +193,6 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
     Rad* __restrict__ radiance = reinterpret_cast<Rad*>(P.radiance);
-    // Bodies for ONE material class of the wavefront kernel's sorted SHADE passes (rt_wavefront.h): a set without scattering kinds has no
-    // BSDF, no unit-ball draw and no continuing lanes at all (every slot ends and regenerates); a set without a Lambert-style or metal
-    // kind has no unit-ball draw.
-    constexpr bool NO_SCATTER = (MATS & ~MATS_TERMINAL) == 0u;
-    constexpr bool NO_BALL = (MATS & ((MATS_DIFFUSE & ~MATS_TERMINAL) | MATBIT(MI355RT_MAT_METAL))) == 0u;
     float4 q0;                                                                            // first 16 bytes of the hit material; read by lanes that loaded it
     if (DEFAULTS) q0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
@@ -235,14 +230,13 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
                 ps.ro = mk(P.cam.position[0], P.cam.position[1], P.cam.position[2]);
                 ps.thr = mk(1.f, 1.f, 1.f); ps.ray_index = 0;
                 if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
-            } else if constexpr (!NO_SCATTER) {
+            } else {
                 scattered = scatter_pre<MATS, WIDE>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
             }
         }
         prof.mark(5);
-        f3 ball = mk(0.f, 0.f, 0.f);
-        if constexpr (!NO_BALL) ball = unit_ball_cooperative<WIDE>(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
-        if (!NO_SCATTER && live && !fresh) {
+        const f3 ball = unit_ball_cooperative<WIDE>(scattered && ball_use != BALL_NONE, ps.rng, lane);   // whole wave, uniform control flow
+        if (live && !fresh) {
             if (scattered) scattered = ball_finish(ball_use, h, ball, fuzz, raw);            // (a fuzzed metal reflection may still be absorbed)
             if (scattered) {
                 ps.thr = ps.thr * atten; ps.ro = scatter_origin(h, side); ++ps.ray_index;
@@ -277,15 +271,14 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
                 n_ro = mk(P.cam.position[0], P.cam.position[1], P.cam.position[2]);
                 n_thr = mk(1.f, 1.f, 1.f); n_ri = 0;
                 if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
-            } else if constexpr (!NO_SCATTER) {
+            } else {
                 scattered = scatter_pre<MATS, WIDE, FASTN>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
             }
         }
         prof.mark(5);
         prof.classes(live && !fresh, live && fresh, __float_as_uint(q0.x));
-        f3 ball = mk(0.f, 0.f, 0.f);
-        if constexpr (!NO_BALL) ball = unit_ball_cooperative<WIDE, TRY1>(scattered && ball_use != BALL_NONE, ps.rng, lane, blk1);   // whole wave, uniform control flow
-        if (!NO_SCATTER && live && !fresh) {
+        const f3 ball = unit_ball_cooperative<WIDE, TRY1>(scattered && ball_use != BALL_NONE, ps.rng, lane, blk1);   // whole wave, uniform control flow
+        if (live && !fresh) {
             if (scattered) scattered = ball_finish<FASTN>(ball_use, h, ball, fuzz, raw);     // (a fuzzed metal reflection may still be absorbed)
             if (scattered) {
                 n_thr = ps.thr * atten; n_ro = scatter_origin(h, side); n_ri = ps.ray_index + 1u;

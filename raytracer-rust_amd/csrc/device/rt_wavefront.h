@@ -38,24 +38,6 @@
 #ifndef MI355RT_AB_WF_WIDE
 #define MI355RT_AB_WF_WIDE true
 #endif
-#ifndef MI355RT_WF_WALK_MIN_ACTIVE
-#define MI355RT_WF_WALK_MIN_ACTIVE 0                        // a WALK pass ends at a round boundary once fewer than this many of its walks are unfinished (0: runs its rounds)
-#endif
-#ifndef MI355RT_WF_REGEN_PENALTY
-#define MI355RT_WF_REGEN_PENALTY 0
-#endif
-#ifndef MI355RT_WF_DRAIN_ROUNDS
-#define MI355RT_WF_DRAIN_ROUNDS 0                           // rounds of a WALK pass once the wave's work cursor is exhausted (0: as always)
-#endif
-#ifndef MI355RT_WF_UNIFORM_WALK
-#define MI355RT_WF_UNIFORM_WALK 0                           // WALK reads the mesh record through scalar loads when every slot of the pass is in the same mesh
-#endif
-#ifndef MI355RT_WF_CLASS_SHADE
-#define MI355RT_WF_CLASS_SHADE 0                            // SHADE bodies per material class: 0 one body, 1 terminal | rest, 2 one per class
-#endif
-#ifndef MI355RT_WF_UNIFORM_FINISH
-#define MI355RT_WF_UNIFORM_FINISH 0                         // SHADE builds the hit record per distinct primitive of the pass from a scalar record
-#endif
 
 namespace mi355rt {
 
@@ -435,13 +417,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #endif
             constexpr uint32_t T0 = MI355RT_WF_T0PRICE;                  // a SHADE pass goes on with the head of the list for the rays it generates
             consider(WQ_SHADE + 3u, cS3, 5u + T0); consider(WQ_SHADE + 2u, cS2, 10u + T0); consider(WQ_SHADE + 1u, cS1, 8u + T0);
-#if MI355RT_WF_REGEN_PENALTY > 0
-            // A/B (round 4): starting new paths is charged a fixed waste, so that a reasonably filled pass over OLD paths goes first and long paths
-            // do not sit in thin queues until the work cursor runs dry.
-            if (cS0 + cF != 0u) { const uint32_t w = (5u + T0) * (64u - min(cS0 + cF, 64u)) + (cF != 0u ? (uint32_t)MI355RT_WF_REGEN_PENALTY : 0u); if (w <= waste) { waste = w; stage = WQ_SHADE; best = cS0 + cF; } }
-#else
             consider(WQ_SHADE, cS0 + cF, 5u + T0);                      // terminal class: free slots ride along (both only regenerate)
-#endif
         }
         if (stage == WQ_NONE) {
             if (wc.exhausted() && __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;   // nothing alive, nothing to start
@@ -500,42 +476,10 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             bool live = have;
             const bool any_hit = have && c.idx != CAND_NONE;
             Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
-#if MI355RT_WF_UNIFORM_FINISH
-            if constexpr (HAS_MESH || MI355RT_WF_UNIFORM_FINISH >= 2) {
-                // One round per distinct winner among the pass's slots, each from a scalar record (the kind is then a scalar branch): a list has
-                // a handful of primitives and a class-sorted pass meets few of them.
-                uint64_t rem = __ballot(any_hit);
-                while (rem != 0ull) {
-                    const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)c.idx, (int)__builtin_ctzll(rem));
-                    const bool mine = any_hit && c.idx == i0;
-                    cprim_t pr = prims + i0;
-                    if (mine) finish_hit_at<HAS_MESH, HAS_MESH ? MI355RT_AB_WF_SHARED_TAIL : true>(pr, P.tris, c, ps.ro, ps.rd, h);
-                    rem &= ~__ballot(mine);
-                }
-            } else
-#endif
             if (any_hit) finish_hit<HAS_MESH, HAS_MESH ? MI355RT_AB_WF_SHARED_TAIL : true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
             // (the priority stays raised through the material read, the radiance store and the work cursor's atomic: shade_and_regenerate
             // drops it to 0 where the arithmetic starts, DROP_PRIO; the list walk below reads primitives again and runs at PRIO_TOP)
-#if MI355RT_WF_CLASS_SHADE
-            {   // `stage` is wave-uniform and the SHADE queues are sorted by material class: each class runs a body instantiated for its kinds only
-                // (scalar branch).  The terminal-class pass -- misses, emitters, free slots -- holds no scatter code at all.
-                [[maybe_unused]] constexpr uint32_t M_DIFF = MATS & MATS_DIFFUSE & ~MATS_TERMINAL, M_ROUGH = MATS & MATS_ROUGH;
-                [[maybe_unused]] constexpr uint32_t M_SPEC = MATS & (MATBIT(MI355RT_MAT_METAL) | MATBIT(MI355RT_MAT_DIELECTRIC));
-#define MI_SHADE(M) shade_and_regenerate<(M), MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true, false, MI355RT_AB_FASTN_WF>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof)
-                if (stage == WQ_SHADE) MI_SHADE(MATS & MATS_TERMINAL);
-#if MI355RT_WF_CLASS_SHADE >= 2
-                else if (stage == WQ_SHADE + 1u) { if constexpr (M_DIFF != 0u) MI_SHADE(M_DIFF); }         // (a class the set does not hold never has a queue entry)
-                else if (stage == WQ_SHADE + 2u) { if constexpr (M_ROUGH != 0u) MI_SHADE(M_ROUGH); }
-                else { if constexpr (M_SPEC != 0u) MI_SHADE(M_SPEC); }
-#else
-                else MI_SHADE(MATS);
-#endif
-#undef MI_SHADE
-            }
-#else
             shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true, false, MI355RT_AB_FASTN_WF>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
-#endif
             if (live) Slot::store_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index);    // a ray to trace: continuing or freshly generated
             const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
             if (lane == 0 && born != died) atomicAdd(&Q.ctrl[16], (uint32_t)(born - died));
@@ -564,24 +508,6 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             MeshTrav m; m.ro = mk(0, 0, 0); m.rd = mk(0, 0, 1); m.ix = m.iy = m.iz = 0.f; m.len_raw = 0.f; m.node = NODE_END; m.best_t = 0.f;
             m.best_tri = 0xFFFFFFFFu; m.leaf_a = m.leaf_b = 0;
             WalkKeep wkeep; wkeep.aux = 0.f; wkeep.w1 = wkeep.w2 = wkeep.cursor_word = 0u;
-#if MI355RT_WF_UNIFORM_WALK
-            {   // The mesh a parked walk is in (the slot's list cursor) is the same for every slot of nearly every pass -- semesterbild has one
-                // mesh, teapot two -- so its record is read ONCE per wave through the constant address space (scalar loads, the matrix in
-                // SGPRs, as TOP reads it) instead of per lane (global loads from per-lane addresses); a pass whose slots are in different
-                // meshes takes the per-lane form.
-                f3 ro_w = mk(0, 0, 0), rd_w = mk(0, 0, 1); uint32_t cur = 0; WalkRec w; w.node = NODE_END; w.best_t = 0.f; w.best_tri = 0xFFFFFFFFu;
-                if (have) Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
-                const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);              // lane 0 holds a slot (n > 0)
-                if (__ballot(have && cur != cur0) == 0ull) {
-                    cprim_t pr = prims + cur0;
-                    if (have) mesh_setup<MI355RT_AB_FAST_MESH_WALK>(pr, ro_w, rd_w, 0.f, m);
-                } else if (have) {
-                    const DevPrim* __restrict__ pr = P.prims + cur;
-                    mesh_setup<MI355RT_AB_FAST_MESH_WALK>(pr, ro_w, rd_w, 0.f, m);
-                }
-                if (have) { m.node = w.node; m.best_t = w.best_t; m.best_tri = w.best_tri; }
-            }
-#else
             if (have) {
                 f3 ro_w, rd_w; uint32_t cur; WalkRec w;
                 Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
@@ -589,7 +515,6 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 mesh_setup<MI355RT_AB_FAST_MESH_WALK>(pr, ro_w, rd_w, 0.f, m);                                                      // the object-space ray, as TOP computed it
                 m.node = w.node; m.best_t = w.best_t; m.best_tri = w.best_tri;
             }
-#endif
 #if MI355RT_WF_SPEC
             // Speculative walk past a leaf.  In the reference's recursion a hit leaf is tested at once, because a triangle hit shrinks
             // t_max for every box that follows (bvh.rs:148-156).  Most leaf tests MISS, and then the walk goes on exactly as if the leaf
@@ -602,15 +527,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             // only extra work.  (Two queued leaves per lane with a leaf phase per queue slot were measured too: the second slot's
             // phases run nearly empty and cost more than the stalls they avoid -- +3 % / +7 %.)
             uint32_t resume = NODE_END; bool stalled = false;
-            const int max_rounds = (MI355RT_WF_DRAIN_ROUNDS > MI355RT_WF_ROUNDS && wc.exhausted()) ? MI355RT_WF_DRAIN_ROUNDS : MI355RT_WF_ROUNDS;
-            for (int round = 0; round < max_rounds; ++round) {
-                const uint64_t walking = __ballot(have && (m.leaf_b != 0u || m.node != NODE_END));
-                if (walking == 0ull) break;
-#if MI355RT_WF_WALK_MIN_ACTIVE > 0
-                // A pass whose walks have mostly finished hands the rest back to the queue (every pending leaf is tested at the end of a round, so a
-                // round boundary is a clean place to park): they come back in a full pass instead of stepping on at a fraction of the lanes.
-                if (round != 0 && (uint32_t)__popcll(walking) < (uint32_t)MI355RT_WF_WALK_MIN_ACTIVE) break;
-#endif
+            for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
+                if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
 #pragma unroll MI355RT_WF_UNROLL
                 for (int u = 0; u < MI355RT_WF_STEPS; ++u) {
                     const bool stepping = have && !stalled && m.node != NODE_END;
