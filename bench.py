@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM
 VALU_SIMDS, VALU_CLOCK_HZ, VALU_CYCLES_PER_WAVE64_INST = 1024, 2.4e9, 2     # 256 CUs x 4 SIMDs; 157.3 TFLOP/s f32 = 1024 x 32 lanes x 2 x 2.4 GHz
 KERNEL_NAMES = {0: "k_render_ctr_nomesh", 1: "k_render_ctr_mesh", 2: "k_render_ctr_sm", 3: "k_render_ctr_simple", 4: "k_render_ctr_sm_fixaabb",
                 5: "k_render_ctr_pool", 6: "k_render_ctr_pool_fixaabb", 7: "k_render_ctr_wf", 8: "k_render_ctr_wf_fixaabb",
-                9: "k_render_ctr_nospec", 10: "k_render_ctr_wf_nometal", 11: "k_render_ctr_wf_meshfree"}
+                9: "k_render_ctr_nospec", 10: "k_render_ctr_wf_nometal", 11: "k_render_ctr_wf_meshfree", 12: "k_render_ctr_wf_nometal_ident"}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
 
 

@@ -192,7 +192,8 @@ static int report_device_error(mi355rt_context* ctx, bool this_render) {
     const unsigned long long n = count - ctx->err_reported;
     ctx->err_reported = count;
     static const char* const kernel_names[KERNEL_VARIANTS] = {"k_render_ctr_nomesh", "k_render_ctr_mesh", "k_render_ctr_sm", "k_render_ctr_simple", "k_render_ctr_sm_fixaabb",
-        "k_render_ctr_pool", "k_render_ctr_pool_fixaabb", "k_render_ctr_wf", "k_render_ctr_wf_fixaabb", "k_render_ctr_nospec", "k_render_ctr_wf_nometal", "k_render_ctr_wf_meshfree"};
+        "k_render_ctr_pool", "k_render_ctr_pool_fixaabb", "k_render_ctr_wf", "k_render_ctr_wf_fixaabb", "k_render_ctr_nospec", "k_render_ctr_wf_nometal", "k_render_ctr_wf_meshfree",
+        "k_render_ctr_wf_nometal_ident"};
     static const struct { uint32_t bit; const char* what; } waits[] = {
         {WAIT_WF_IDLE, "idle: no progress in the workgroup"}, {WAIT_WF_RING, "ring entry: a reserved ticket was never written, or an entry never emptied"},
         {WAIT_WF_FOLLOWED, "waves that followed their workgroup's error flag out"},
@@ -347,6 +348,13 @@ int flatten_meshes(const mi355rt_scene* sc, std::vector<DevNode>& out_nodes, std
     return MI355RT_OK;
 }
 
+// Is a mesh untransformed?  world_to_object (column-major, w2o[4 * column + row]) with a diagonal of exact ones, exact zeros (of either sign) off the
+// diagonal of the upper 3 x 3 and a zero translation: the case rt_intersect.h's ray_nonzero_finite() reasons about.
+bool xform_is_identity(const float* w2o) {
+    for (int k : {4, 8, 1, 9, 2, 6, 12, 13, 14}) if (w2o[k] != 0.0f) return false;            // (NaN != 0 too)
+    return w2o[0] == 1.0f && w2o[5] == 1.0f && w2o[10] == 1.0f;
+}
+
 // The 6 world normals a cube hit can produce (cube.rs:105-136): normalized(world_to_object^T * (+-e_k, 0)) with
 // exactly the device's operation order (xform_normal + normalized in rt_intersect.h / rt_math.h; this file is compiled
 // with -ffp-contract=off too), so the kernel can select instead of recomputing sqrt and divide per hit.
@@ -396,6 +404,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     if (sc->n_meshes && (!sc->meshes || !sc->nodes || !sc->triangles || (!sc->tri_indices && sc->n_tri_indices))) return fail(MI355RT_ERR_INVALID, "mesh arrays are null");
     { int rc = flatten_meshes(sc, nodes, tris, mesh_roots); if (rc) return rc; }
     std::vector<DevPrim> prims(sc->n_primitives);
+    bool all_meshes_identity = true;
     for (uint32_t i = 0; i < sc->n_primitives; ++i) {
         const mi355rt_primitive& p = sc->primitives[i];
         DevPrim& d = prims[i];
@@ -427,6 +436,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
             if (p.kind == MI355RT_PRIM_MESH) {
                 if (p.mesh >= sc->n_meshes) return fail(MI355RT_ERR_INVALID, "primitive mesh index");
                 d.node_begin = mesh_roots[p.mesh];
+                all_meshes_identity = all_meshes_identity && xform_is_identity(w2o);
             }
         } else {
             std::memcpy(d.d, p.data, 32 * sizeof(float));
@@ -478,7 +488,8 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     // families the most pruned instantiation whose material set covers the scene's (rt_device.h, mats_of_variant): the branches of
     // the kinds a scene does not have are compiled out -- they set the register peak.  The library reads NO environment
     // variables; the diagnostic hook mi355rt_debug_set_knob("kernel", v) may name another variant this library was built with.
-    if (has_mesh) ctx->variant = covers(KERNEL_WAVEFRONT_NOMETAL) ? KERNEL_WAVEFRONT_NOMETAL : KERNEL_WAVEFRONT;
+    // ... and, where the meshes are all untransformed (OBJ data in world space: teapot), the instantiation whose mesh_setup skips the matrix products.
+    if (has_mesh) ctx->variant = covers(KERNEL_WAVEFRONT_NOMETAL) ? (all_meshes_identity ? KERNEL_WAVEFRONT_NOMETAL_IDENT : KERNEL_WAVEFRONT_NOMETAL) : KERNEL_WAVEFRONT;
     else {
         // Mesh-free lists run on a lockstep kernel -- unless the shading step diverges EXPENSIVELY: a rough conductor (ln, atan, two
         // sin_cos, the conductor's Fresnel term: ~400 instructions) next to another scattering material.  In lockstep a wave pays that branch
@@ -494,8 +505,10 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         const uint32_t v = (uint32_t)ctx->forced_variant;
         const bool mesh_free_only = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_MESHFREE;
         const bool selectable = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || v == KERNEL_POOL || v == KERNEL_WAVEFRONT ||
-                                v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_NOMETAL || v == KERNEL_WAVEFRONT_MESHFREE;   // (the _FIXAABB forms follow options.flags)
-        const bool ok = render_ctr_variant_built(v) && selectable && covers(v) && !(mesh_free_only && has_mesh) && !(v == KERNEL_POOL && !has_mesh);
+                                v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_NOMETAL || v == KERNEL_WAVEFRONT_MESHFREE ||
+                                v == KERNEL_WAVEFRONT_NOMETAL_IDENT;   // (the _FIXAABB forms follow options.flags)
+        const bool ok = render_ctr_variant_built(v) && selectable && covers(v) && !(mesh_free_only && has_mesh) && !(v == KERNEL_POOL && !has_mesh) &&
+                        !(v == KERNEL_WAVEFRONT_NOMETAL_IDENT && !(has_mesh && all_meshes_identity));     // (that form ASSUMES untransformed meshes)
         if (ok) ctx->variant = v;
     }
     // Root-box test right at mesh set-up (reference build's kernels): the pool kernel always (rays that miss the root never leave

@@ -143,7 +143,8 @@ enum : uint32_t {
     KERNEL_LOCKSTEP_NOSPEC = 9,  // KERNEL_LOCKSTEP without the metal and dielectric branches: 72 VGPRs = 7 waves per SIMD (veach-mis)
     KERNEL_WAVEFRONT_NOMETAL = 10,   // KERNEL_WAVEFRONT without the metal branch (teapot, semesterbild)
     KERNEL_WAVEFRONT_MESHFREE = 11,  // the wavefront for lists WITHOUT a mesh, no metal / dielectric: material-sorted SHADE passes for scenes whose materials diverge (veach-mis)
-    KERNEL_VARIANTS = 12
+    KERNEL_WAVEFRONT_NOMETAL_IDENT = 12,   // KERNEL_WAVEFRONT_NOMETAL for lists whose meshes are all untransformed (teapot): mesh_setup without its matrix products
+    KERNEL_VARIANTS = 13
 };
 // Material sets (bit k = kind MI355RT_MAT_k may occur) the kernels are instantiated for; set_scene picks, per kernel family, the
 // most pruned instantiation whose set covers the scene's materials.  The branches compiled out set the register peak.
@@ -157,7 +158,7 @@ constexpr uint32_t MATS_NO_METAL = MATS_ALL & ~MATBIT(MI355RT_MAT_METAL);
 constexpr uint32_t MATS_NO_SPECULAR = MATS_ALL & ~(MATBIT(MI355RT_MAT_METAL) | MATBIT(MI355RT_MAT_DIELECTRIC));
 inline uint32_t mats_of_variant(uint32_t variant) {
     return variant == KERNEL_LOCKSTEP_SIMPLE ? MATS_LAMBERT : (variant == KERNEL_LOCKSTEP_NOSPEC || variant == KERNEL_WAVEFRONT_MESHFREE) ? MATS_NO_SPECULAR
-         : variant == KERNEL_WAVEFRONT_NOMETAL ? MATS_NO_METAL : MATS_ALL;
+         : (variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_NOMETAL_IDENT) ? MATS_NO_METAL : MATS_ALL;
 }
 
 struct ResolveParams {
@@ -233,7 +234,7 @@ static_assert(WF_FIXED_WORDS <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budge
 constexpr uint32_t WF_LDS_NODES = MI355RT_WF_LDS_NODES >= 0 ? (uint32_t)MI355RT_WF_LDS_NODES : (WF_LDS_BUDGET_WORDS - WF_FIXED_WORDS) / 8u;    // 32-byte nodes
 static_assert(WF_FIXED_WORDS + 8u * WF_LDS_NODES <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budget (node copy)");
 constexpr uint32_t STATS_WORDS = 40;                         // u64 device counters per render: [0] paths, [1] rays, the rest diagnostic builds only
-inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB || variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_MESHFREE; }
+inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB || variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_MESHFREE || variant == KERNEL_WAVEFRONT_NOMETAL_IDENT; }
 // The mesh-free form runs 2 x 16 waves per CU at 64 VGPRs (8 per SIMD): veach-mis 16.71 -> 16.09 ms; the forms with the BVH walk lose a third
 // there (42 spilled registers).  Waves per workgroup must be a multiple of 4: a workgroup's waves are dealt round-robin over the CU's
 // four SIMDs, and with 10, 13 or 14 of them the second workgroup no longer fits the per-SIMD wave budget (measured: +40 %; this also explains

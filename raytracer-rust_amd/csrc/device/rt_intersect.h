@@ -129,6 +129,17 @@ template <class PrimPtr> DI f3 xform_normal(PrimPtr pr, f3 n) {               //
 }
 DI float glam_signum(float v) { if (v != v) return v; return copysignf(1.0f, v); }
 
+// Untransformed meshes (world_to_object == identity; the host checks it: rt_api.cpp xform_is_identity).  glam's Mat4 * Vec4 computes, per component,
+// ((1*x + (+-0)*y) + (+-0)*z) + (+-0): for finite y, z the middle terms are zeros, and x + (+-0) == x for every x != 0 -- the object-space ray IS the
+// world-space ray, bit for bit, unless a component is a zero (whose SIGN the sum could change) or not finite (0 * inf = NaN).  The kernels instantiated
+// for such scenes (MESH_IDENT) therefore skip the two matrix products of mesh_setup for waves whose rays all pass this test, and take the general
+// form otherwise -- a wave-uniform choice, once per pass.
+DI bool ray_nonzero_finite(f3 ro, f3 rd) {
+    const float mn = fminf(fminf(fminf(fabsf(ro.x), fabsf(ro.y)), fabsf(ro.z)), fminf(fminf(fabsf(rd.x), fabsf(rd.y)), fabsf(rd.z)));
+    const float mx = fmaxf(fmaxf(fmaxf(fabsf(ro.x), fabsf(ro.y)), fabsf(ro.z)), fmaxf(fmaxf(fabsf(rd.x), fabsf(rd.y)), fabsf(rd.z)));
+    return (mn > 0.0f) && (mx < __builtin_inff()) && !has_nan(ro) && !has_nan(rd);              // (fminf / fmaxf ignore a NaN operand: tested apart)
+}
+
 // objects/cube.rs:59-158, the part that decides whether and where the cube is hit; the face normal (cube.rs:105-143) is
 // computed by finish_hit() for the winner only.
 DI uint32_t cube_axis(f3 po) {                                                          // cube.rs:112-133 as selects
@@ -201,10 +212,12 @@ struct MeshTrav {
 };
 // FAST: the short reciprocal / square root of rt_math.h (same bits; a template argument because the kernels' register allocation
 // decides whether the shorter code is also the faster one).
+// identity (wave-uniform): the mesh is untransformed and every active lane's ray passed ray_nonzero_finite()
 template <bool FAST = false, class PrimPtr>
-DI void mesh_setup(PrimPtr pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m) {   // mesh_object.rs:264-291
-    m.ro = xform_w2o_point(pr, ro_w);
-    f3 rd_raw = xform_w2o_dir(pr, rd_w);
+DI void mesh_setup(PrimPtr pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m, bool identity = false) {   // mesh_object.rs:264-291
+    f3 rd_raw;
+    if (identity) { m.ro = ro_w; rd_raw = rd_w; }
+    else { m.ro = xform_w2o_point(pr, ro_w); rd_raw = xform_w2o_dir(pr, rd_w); }
     m.len_raw = len(rd_raw);
     if constexpr (FAST) {
         const f3 once = (m.len_raw < EPS) ? rd_raw : rd_raw * recip_normal_range(m.len_raw);     // normalized(): the length is the one above

@@ -257,7 +257,8 @@ struct WfQueues {
 
 // HAS_MESH = false: the same wavefront for lists without a mesh (picked when the materials of such a scene diverge): no
 // WALK / TOP1 stages, 16-word slots (no walk state), 1 023 of them.
-template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true, bool COMPACT = false>
+// MESH_IDENT: every mesh of the list is untransformed (the host picks this instantiation then): see ray_nonzero_finite() in rt_intersect.h.
+template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true, bool COMPACT = false, bool MESH_IDENT = false>
 DI void render_ctr_wavefront(const RenderParams& P) {
     static_assert(HAS_MESH || !COMPACT, "the mesh-free form has no walk state to pack");
     typedef SlotIO<COMPACT> Slot;
@@ -318,6 +319,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
     // have just generated (still in registers) and by TOP1 passes on the slots whose walk is back.
     auto run_top = [&](const bool have, const f3 ro, const f3 rd, Cand c, uint32_t cursor, bool walk_done, uint32_t ray_index, WalkRec wk, uint32_t* sl, const uint32_t id) {
         bool to_walk = false;
+        bool ident_ok = false;
+        if constexpr (MESH_IDENT) ident_ok = __ballot(have && !ray_nonzero_finite(ro, rd)) == 0ull;
         for (uint32_t i = 0; i < P.n_prims; ++i) {
             const bool mine = have && !to_walk && cursor == i;
             if (__ballot(mine) == 0ull) continue;
@@ -332,7 +335,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                     default:
                         if constexpr (!HAS_MESH) break;                // (the host picks this instantiation for mesh-free lists only)
                         else if (!walk_done) {
-                            MeshTrav mt; mesh_setup<MI355RT_AB_FAST_MESH_TOP>(pr, ro, rd, c.t, mt);
+                            MeshTrav mt; mesh_setup<MI355RT_AB_FAST_MESH_TOP>(pr, ro, rd, c.t, mt, ident_ok);
                             const uint32_t root = mt.node;
                             mesh_step<FIXED_AABB, WF_LDS_MODE>(n4, lds, lds_count, EPS, mt);       // the root box, here: most rays miss it
                             if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
@@ -361,7 +364,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                                 if (!parked) { to_walk = true; advance = false; }
                             }
                         } else {
-                            MeshTrav mt; mt.best_t = wk.best_t; mt.best_tri = wk.best_tri; mt.len_raw = len(xform_w2o_dir(pr, rd));   // mesh_object.rs:288, again
+                            MeshTrav mt; mt.best_t = wk.best_t; mt.best_tri = wk.best_tri; mt.len_raw = len(ident_ok ? rd : xform_w2o_dir(pr, rd));   // mesh_object.rs:288, again
                             mesh_accept(i, mt, rd, EPS, c); walk_done = false;
                         }
                         break;
@@ -508,7 +511,15 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             MeshTrav m; m.ro = mk(0, 0, 0); m.rd = mk(0, 0, 1); m.ix = m.iy = m.iz = 0.f; m.len_raw = 0.f; m.node = NODE_END; m.best_t = 0.f;
             m.best_tri = 0xFFFFFFFFu; m.leaf_a = m.leaf_b = 0;
             WalkKeep wkeep; wkeep.aux = 0.f; wkeep.w1 = wkeep.w2 = wkeep.cursor_word = 0u;
-            if (have) {
+            if constexpr (MESH_IDENT) {
+                // untransformed meshes: the object-space ray is the slot's ray -- no record read, no matrix products -- for passes whose rays all
+                // pass the test TOP applied to the same rays; the general form otherwise
+                f3 ro_w = mk(0, 0, 0), rd_w = mk(0, 0, 1); uint32_t cur = 0; WalkRec w; w.node = NODE_END; w.best_t = 0.f; w.best_tri = 0xFFFFFFFFu;
+                if (have) Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
+                if (__ballot(have && !ray_nonzero_finite(ro_w, rd_w)) == 0ull) { if (have) mesh_setup<MI355RT_AB_FAST_MESH_WALK>(P.prims, ro_w, rd_w, 0.f, m, true); }
+                else if (have) mesh_setup<MI355RT_AB_FAST_MESH_WALK>(P.prims + cur, ro_w, rd_w, 0.f, m);
+                if (have) { m.node = w.node; m.best_t = w.best_t; m.best_tri = w.best_tri; }
+            } else if (have) {
                 f3 ro_w, rd_w; uint32_t cur; WalkRec w;
                 Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
                 const DevPrim* __restrict__ pr = P.prims + cur;                                          // lanes may be in different meshes
@@ -639,9 +650,11 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #ifndef MI355RT_AB_WF_MATS
 #define MI355RT_AB_WF_MATS MATS_ALL
 #endif
-// Entry points: one body per material set (rt_device.h); the opt-in slab test only in the general form.
+// Entry points: one body per material set (rt_device.h) -- and, for the set the mesh scenes use, per transform class of the meshes; the opt-in slab test only in the general form.
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MATS>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS, true, MI355RT_AB_WF_COMPACT>(P); }
+// ... and for lists whose meshes are all untransformed (teapot -1.9 % at 256 spp; profiles/r04/ab_wavefront_transform_classes.txt)
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_ident(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS, true, false, true>(P); }
 #ifndef MI355RT_OCC_WF_MESHFREE
 #define MI355RT_OCC_WF_MESHFREE 8
 #endif

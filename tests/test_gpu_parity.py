@@ -128,8 +128,13 @@ def test_mesh_kernels_equal_the_lockstep_walk(name, native, oracle_mod, abi, kno
     sc = load_for_both(name, oracle_mod, host, width=96, height=64, spp=6, max_depth=12)
     ctx = device.Context(0)
     ctx.set_scene(sc, sc.camera, sc.settings)
-    assert ctx.kernel_variant() == 10                      # neither scene has a metal: the wavefront kernel without that branch is the automatic choice
+    # neither scene has a metal: the wavefront kernel without that branch is the automatic choice -- for teapot, whose two meshes are untransformed,
+    # in the instantiation that skips mesh_setup's matrix products (12); forcing 10 / 7 on it runs the general forms, which must agree bit for bit
+    assert ctx.kernel_variant() == (12 if name == "teapot" else 10)
     ctx.close()
+    if name == "semesterbild":                             # its mesh is rotated: the form for untransformed meshes must be refused, not run
+        knobs(None, kernel=12)
+        ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings); assert ctx.kernel_variant() == 10; ctx.close()
     outs = []
     for library, kv in ((None, {"kernel": 1}), (None, {}), (None, {"kernel": 7}), (None, {"kernel": 10}),
                         (R, {"kernel": 1}), (R, {"kernel": 7}),
@@ -215,7 +220,7 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, knobs):
     # ... and a mesh-free wavefront kernel is refused for a list with a mesh
     st = load_for_both("teapot", oracle_mod, host, width=48, height=32, spp=2, max_depth=4)
     knobs(kernel=11)
-    assert run(st)[0] == 10
+    assert run(st)[0] == 12                                # (teapot's automatic choice: untransformed meshes)
 
 
 def test_fixed_wo3_reader_scene_is_bit_identical_to_the_oracle(native, oracle_mod, abi):
@@ -318,3 +323,26 @@ def test_caller_built_bvh_with_fat_leaves(kernel, native, oracle_mod, abi, knobs
                     lambda n: list(range(n)))
     # the mesh is visible at all: the images are not just sky, and the three trees give practically the same picture
     assert np.abs(one_leaf[1] - base[1]).mean() < 1e-3 and np.abs(two[1] - base[1]).mean() < 1e-3
+
+
+def test_untransformed_mesh_form_and_its_fallback_for_rays_with_zero_components(native, oracle_mod, abi, knobs):
+    """k_render_ctr_wf_nometal_ident (variant 12) replaces mesh_setup's matrix products by the ray itself where every mesh of the list is untransformed --
+    exact only for rays without a zero or non-finite component (rt_intersect.h ray_nonzero_finite), so a wave that holds such a ray takes the general
+    form.  A camera ON the plane x = 0 makes every primary ray start at x == 0 (general form), while the bounced rays take the short form: both forms
+    inside one render, and the image must be the oracle's and the general kernel's, bit for bit (mesh_object.rs:264-291)."""
+    from oracle import scene_loader as L
+    host, device = native
+    F = np.float32
+    sc = load_for_both("teapot", oracle_mod, host, width=72, height=54, spp=5, max_depth=10)
+    sc.camera = L.camera_new((0.0, 2.0, 9.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), F(45.0), F(72 / 54))
+    outs = []
+    for kv in ({}, {"kernel": 10}, {"kernel": 7}, {"kernel": 1}):
+        knobs(None, **kv)
+        ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings)
+        assert ctx.kernel_variant() == kv.get("kernel", 12)
+        ctx.close()
+        outs.append(device.render(sc, sc.camera, sc.settings, abi.Options.make()))
+    op, ol, cnt = oracle_mod.render(sc, sc.camera, sc.settings, abi.Options.make())
+    assert cnt.rays > 1.2 * cnt.samples                                          # the view does hit the meshes and bounce
+    for gp, gl, st in outs:
+        assert st.rays == cnt.rays and np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op)

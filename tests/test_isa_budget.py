@@ -16,6 +16,7 @@ BUDGET = {
     "k_render_ctr_nospec": (72, 7, 21 * 1024, 5),
     "k_render_ctr_nomesh": (80, 5, 23 * 1024, 4),
     "k_render_ctr_wf_nometal": (80, 8, 50 * 1024, 6),       # teapot, semesterbild: 6 waves per SIMD, 2 workgroups of 12 waves per CU
+    "k_render_ctr_wf_nometal_ident": (80, 8, 52 * 1024, 6),   # teapot: the same for untransformed meshes
     "k_render_ctr_wf": (80, 12, 51 * 1024, 15),
     "k_render_ctr_wf_meshfree": (64, 16, 25 * 1024, 22),    # veach-mis: 8 waves per SIMD
     "k_resolve": (16, 0, 2 * 1024, 0),
