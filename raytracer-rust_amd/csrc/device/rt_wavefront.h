@@ -258,7 +258,9 @@ struct WfQueues {
 // HAS_MESH = false: the same wavefront for lists without a mesh (picked when the materials of such a scene diverge): no
 // WALK / TOP1 stages, 16-word slots (no walk state), 1 023 of them.
 // MESH_IDENT: every mesh of the list is untransformed (the host picks this instantiation then): see ray_nonzero_finite() in rt_intersect.h.
-template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true, bool COMPACT = false, bool MESH_IDENT = false>
+// INLINE_STEPS: box tests of a walk that TOP runs itself when at least half the wave is inside the root box (8; 12 measured better for the deep trees of the
+// scene the MESH_IDENT form serves: teapot -0.7 %, and worse for semesterbild's shallower one: +0.8 %).
+template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true, bool COMPACT = false, bool MESH_IDENT = false, int INLINE_STEPS = 0>
 DI void render_ctr_wavefront(const RenderParams& P) {
     static_assert(HAS_MESH || !COMPACT, "the mesh-free form has no walk state to pack");
     typedef SlotIO<COMPACT> Slot;
@@ -349,7 +351,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                                 bool parked = false;
                                 if (MI355RT_WF_INLINE_MIN <= 64 && (uint32_t)__popcll(__ballot(true)) >= (uint32_t)MI355RT_WF_INLINE_MIN) {
 #pragma unroll 1
-                                    for (int u = 0; u < MI355RT_WF_INLINE_STEPS; ++u) {
+                                    for (int u = 0; u < (INLINE_STEPS > 0 ? INLINE_STEPS : MI355RT_WF_INLINE_STEPS); ++u) {
                                         if (mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
                                         if (mt.node == NODE_END) break;
                                         MI355RT_WFCOUNT(7, (uint32_t)__popcll(__ballot(true)));
@@ -519,7 +521,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 if (__ballot(have && !ray_nonzero_finite(ro_w, rd_w)) == 0ull) { if (have) mesh_setup<MI355RT_AB_FAST_MESH_WALK>(P.prims, ro_w, rd_w, 0.f, m, true); }
                 else if (have) mesh_setup<MI355RT_AB_FAST_MESH_WALK>(P.prims + cur, ro_w, rd_w, 0.f, m);
                 if (have) { m.node = w.node; m.best_t = w.best_t; m.best_tri = w.best_tri; }
-            } else if (have) {
+            }
+            else if (have) {
                 f3 ro_w, rd_w; uint32_t cur; WalkRec w;
                 Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
                 const DevPrim* __restrict__ pr = P.prims + cur;                                          // lanes may be in different meshes
@@ -653,8 +656,8 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 // Entry points: one body per material set (rt_device.h) -- and, for the set the mesh scenes use, per transform class of the meshes; the opt-in slab test only in the general form.
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MATS>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS, true, MI355RT_AB_WF_COMPACT>(P); }
-// ... and for lists whose meshes are all untransformed (teapot -1.9 % at 256 spp; profiles/r04/ab_wavefront_transform_classes.txt)
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_ident(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS, true, false, true>(P); }
+// ... and for lists whose meshes are all untransformed (teapot -1.9 % at 256 spp, another -0.7 % with 12 inline steps; profiles/r04/ab_wavefront_transform_classes.txt)
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_ident(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS, true, false, true, 12>(P); }
 #ifndef MI355RT_OCC_WF_MESHFREE
 #define MI355RT_OCC_WF_MESHFREE 8
 #endif
