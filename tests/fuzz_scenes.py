@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 
-def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60, only_kinds=None, lambert_only=False):
+def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60, only_kinds=None, lambert_only=False, identity_meshes=False, no_metal=False):
     from oracle import scene_loader as L
     rng = np.random.default_rng(seed)
     F = np.float32
@@ -25,6 +25,8 @@ def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60, only_kin
     if lambert_only:                                                 # what the Lambert-only lockstep kernel (k_render_ctr_simple) is picked for:
         del mats[:]                                                  # the materials ARRAY holds nothing but Lambert (solid) / Emissive / Null
         kinds = [mat(abi.MAT_LAMBERT_SOLID, col()), mat(abi.MAT_EMISSIVE, tuple(rng.uniform(1, 6, 3))), mat(abi.MAT_NULL), mat(abi.MAT_LAMBERT_SOLID, col())]
+    if no_metal:                                                     # the wavefront kernels' pruned instantiations: no MI355RT_MAT_METAL in the list
+        kinds = [k for k in kinds if mats[k].kind != abi.MAT_METAL]
     if not exact_only:
         cu = ((0.2, 1.09, 1.42), (3.91, 2.57, 2.30))
         kinds += [mat(abi.MAT_ROUGH_GGX, col(), p0=rng.uniform(0.02, 0.5), eta=cu[0], k=cu[1]),
@@ -53,6 +55,9 @@ def random_scene(abi, host, seed, exact_only, n_prims=14, mesh_tris=60, only_kin
             m = matrix(); p.data[0:16] = [float(v) for v in m]; p.data[16:32] = [float(v) for v in L.mat4_inverse(m)]
         else:
             m = matrix(); p.data[0:16] = [float(v) for v in m]; p.data[16:32] = [float(v) for v in L.mat4_inverse(m)]
+            if identity_meshes:                                        # untransformed meshes (OBJ data in world space): what k_render_ctr_wf_nometal_ident is picked for
+                ident = [1.0 if (k % 5) == 0 else 0.0 for k in range(16)]
+                p.data[0:16] = ident; p.data[16:32] = ident
             nt = mesh_tris if mesh_tris > 0 else int(rng.integers(1, 4))          # mesh_tris <= 0: tiny meshes of 1..3 triangles
             v = rng.uniform(-1, 1, size=(nt, 3, 3)).astype(F)
             v[: nt // 4, :, 2] = F(0.25)                                   # a coplanar patch: zero-thickness leaf boxes (App. B-1)

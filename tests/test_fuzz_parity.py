@@ -99,3 +99,35 @@ def test_lockstep_kernels_on_mesh_free_fuzz_scenes(label, kw, kernel, seed, nati
         op, ol, cnt = oracle_mod.render(sc, sc.camera, st, opt)
         assert stats.rays == cnt.rays, label
         assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op), label
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(40, 52)))
+def test_untransformed_mesh_kernel_on_fuzz_scenes(seed, native, oracle_mod, abi):
+    """k_render_ctr_wf_nometal_ident (variant 12) is picked for lists whose meshes are all untransformed and that hold no metal.  Random lists of
+    that shape -- meshes next to every other primitive kind, every other material -- with the fuzz scenes' camera ON the plane x = 0 (so that every
+    primary ray has a zero component and takes the general form of mesh_setup, the bounced rays the short one) must match the oracle bit for bit and
+    must really have run on that kernel; the general instantiation (10) forced on the same scene gives the same image (mesh_object.rs:264-291)."""
+    host, device = native
+    shapes = [dict(n_prims=9, mesh_tris=80), dict(n_prims=5, only_kinds=[4, 4, 2], mesh_tris=300), dict(n_prims=14, only_kinds=[4, 3, 0, 4, 2, 1], mesh_tris=30)]
+    sc = random_scene(abi, host, seed, exact_only=True, identity_meshes=True, no_metal=True, **shapes[seed % 3])
+    st = abi.Settings(56 + seed % 9, 40 + seed % 7, 4 + seed % 3, 3 + seed % 9)
+    opt = abi.Options.make()
+    op, ol, cnt = oracle_mod.render(sc, sc.camera, st, opt)
+    for forced in (None, 10):
+        ctx = device.Context(0)
+        try:
+            if forced is not None:
+                ctx.set_knob("kernel", forced)
+            ctx.set_scene(sc, sc.camera, st)
+            assert ctx.kernel_variant() == (12 if forced is None else forced)
+        finally:
+            ctx.close()
+        if forced is not None:
+            device.set_knob("kernel", forced)
+        try:
+            gp, gl, stats = device.render(sc, sc.camera, st, opt)
+        finally:
+            device.clear_knobs()
+        assert stats.rays == cnt.rays, (seed, forced)
+        assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gp, op), (seed, forced)

@@ -14,7 +14,8 @@ bad = 0; t0 = time.time()
 for seed in range(first, first + n):
     shapes = [dict(), dict(n_prims=5, mesh_tris=400), dict(n_prims=30, mesh_tris=10), dict(n_prims=8, only_kinds=[4, 3, 4, 2], mesh_tris=150),
               dict(n_prims=5 + seed % 19, only_kinds=[[2, 2, 3, 0, 1, 3, 3, 0, 0, 2, 1, 1], [3, 2, 0, 1], [0, 0, 3], [2, 3, 3, 1]][seed // 6 % 4]),   # mesh-free: general lockstep kernel
-              dict(n_prims=4 + seed % 13, only_kinds=[[2, 2, 2, 3, 3, 2, 0, 1, 3], [3], [2, 3]][seed // 6 % 3], lambert_only=True)]          # Lambert-only lockstep kernel
+              dict(n_prims=4 + seed % 13, only_kinds=[[2, 2, 2, 3, 3, 2, 0, 1, 3], [3], [2, 3]][seed // 6 % 3], lambert_only=True),          # Lambert-only lockstep kernel
+              dict(n_prims=5 + seed % 11, mesh_tris=20 + seed % 200, identity_meshes=True, no_metal=True)]                                      # untransformed meshes, no metal: k_render_ctr_wf_nometal_ident
     kw = shapes[seed % len(shapes)]
     rough = seed % 5 == 4                                  # every fifth scene has GGX / Beckmann rough conductors too: only the reference-stream
     sc = random_scene(abi, host, seed, exact_only=not rough, **kw)   # mode is bit-exact there (ln / atan / sin / cos rounded once from double on both sides)
