@@ -416,7 +416,11 @@ def self_launch(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # before any child initialises HIP (see main)
     env["MI355RT_BENCH_LAUNCH"] = f"self: bench.py --gpus {n} started torch.distributed.run ({n} fresh child process(es), 127.0.0.1)"
-    rc, saw = run_relay(launcher_command(n, argv), env)
+    try:
+        rc, saw = run_relay(launcher_command(n, argv), env)
+    except OSError as e:                                     # the launcher itself could not be started (not found, no more processes, ...)
+        print(f"bench.py: could not start the launcher: {e}", file=sys.stderr, flush=True)
+        rc, saw = 127, False
     if rc == 0 and saw:
         return 0
     if n > 1 and os.environ.get("MI355RT_BENCH_NO_FALLBACK") != "1":

@@ -68,6 +68,13 @@ def test_failed_launch_relays_the_code_or_falls_back_to_one_process(tmp_path):
     assert "no GPU visible" in out.stderr
 
 
+def test_a_launcher_that_cannot_be_started_is_a_failed_launch(tmp_path):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MI355RT_BENCH_FORCE_DIST", "MI355RT_BENCH_REHEARSE")}
+    env.update(MI355RT_BENCH_LAUNCHER=str(tmp_path / "no_such_launcher"), MI355RT_BENCH_NO_FALLBACK="1")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 127 and "could not start the launcher" in out.stderr and "Traceback" not in out.stderr
+
+
 def test_under_a_launcher_nothing_is_launched(tmp_path):
     # RANK in the environment = a launcher (the driver's torch.distributed.run) is already around this process: it is a rank, not a parent.
     # Without a GPU the rank stops at "no GPU visible"; the stub must not have been started.
