@@ -129,7 +129,6 @@ struct mi355rt_context {
     uint32_t guided_mult = 16;           // run length = (left in shard) / (guided_mult * waves per shard); 16 measured best at 1/8-image launches
     uint32_t inline_steps = 0;           // 1 when several meshes share the list (many rays miss a mesh's root box: teapot +5..12 %), 0 for a single mesh (semesterbild -10 % otherwise)
     uint32_t trav_min = 24;              // measured optimum 24-32 on semesterbild / teapot (tools/ab_kernel.py)
-    uint32_t walker_waves = 4, pool_patience = 64;   // pool kernel (KERNEL_POOL): walker waves per workgroup, polls before an under-filled pass
     bool have_scene = false;
     mi355rt_settings settings{};
     DevCamera cam{};
@@ -167,7 +166,7 @@ struct mi355rt_context {
     uint32_t spin_limit_idle = SPIN_LIMIT_IDLE, spin_limit_entry = SPIN_LIMIT_ENTRY;   // diagnostic knobs "spin_idle" / "spin_entry"
     uint32_t launched_variants = 0;      // bit v: kernel variant v was launched since the last failure report (names the kernel in the message)
     int forced_variant = -1;             // diagnostic knob "kernel": applied by set_scene when the scene allows it
-    int knob_inline_steps = -1;          // diagnostic knob "inline_steps" (reference build's state machine / pool kernels)
+    int knob_inline_steps = -1;          // diagnostic knob "inline_steps" (reference build's state machine)
     // timing pool (mi355rt_context_set_timing): event triples recorded around every kernel pair without
     // synchronising; mi355rt_context_read_timing sums them after the caller's own stream sync.
     bool timing = false;
@@ -192,12 +191,11 @@ static int report_device_error(mi355rt_context* ctx, bool this_render) {
     const unsigned long long n = count - ctx->err_reported;
     ctx->err_reported = count;
     static const char* const kernel_names[KERNEL_VARIANTS] = {"k_render_ctr_nomesh", "k_render_ctr_mesh", "k_render_ctr_sm", "k_render_ctr_simple", "k_render_ctr_sm_fixaabb",
-        "k_render_ctr_pool", "k_render_ctr_pool_fixaabb", "k_render_ctr_wf", "k_render_ctr_wf_fixaabb", "k_render_ctr_nospec", "k_render_ctr_wf_nometal", "k_render_ctr_wf_meshfree",
+        "(retired)", "(retired)", "k_render_ctr_wf", "k_render_ctr_wf_fixaabb", "k_render_ctr_nospec", "k_render_ctr_wf_nometal", "k_render_ctr_wf_meshfree",
         "k_render_ctr_wf_nometal_ident"};
     static const struct { uint32_t bit; const char* what; } waits[] = {
         {WAIT_WF_IDLE, "idle: no progress in the workgroup"}, {WAIT_WF_RING, "ring entry: a reserved ticket was never written, or an entry never emptied"},
-        {WAIT_WF_FOLLOWED, "waves that followed their workgroup's error flag out"},
-        {WAIT_POOL_RESULTS, "pool producer: walk results did not come back"}, {WAIT_POOL_WALKER_IDLE, "pool walker: neither requests nor progress"}};
+        {WAIT_WF_FOLLOWED, "waves that followed their workgroup's error flag out"}};
     std::string kernels, which;
     for (uint32_t v = 0; v < KERNEL_VARIANTS; ++v) if ((ctx->launched_variants >> v) & 1u) kernels += std::string(kernels.empty() ? "" : ", ") + kernel_names[v] + " (variant " + std::to_string(v) + ")";
     ctx->launched_variants = 0;
@@ -504,17 +502,16 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     if (ctx->forced_variant >= 0) {
         const uint32_t v = (uint32_t)ctx->forced_variant;
         const bool mesh_free_only = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_MESHFREE;
-        const bool selectable = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || v == KERNEL_POOL || v == KERNEL_WAVEFRONT ||
+        const bool selectable = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || v == KERNEL_WAVEFRONT ||
                                 v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_NOMETAL || v == KERNEL_WAVEFRONT_MESHFREE ||
                                 v == KERNEL_WAVEFRONT_NOMETAL_IDENT;   // (the _FIXAABB forms follow options.flags)
-        const bool ok = render_ctr_variant_built(v) && selectable && covers(v) && !(mesh_free_only && has_mesh) && !(v == KERNEL_POOL && !has_mesh) &&
+        const bool ok = render_ctr_variant_built(v) && selectable && covers(v) && !(mesh_free_only && has_mesh) &&
                         !(v == KERNEL_WAVEFRONT_NOMETAL_IDENT && !(has_mesh && all_meshes_identity));     // (that form ASSUMES untransformed meshes)
         if (ok) ctx->variant = v;
     }
-    // Root-box test right at mesh set-up (reference build's kernels): the pool kernel always (rays that miss the root never leave
-    // their wave: 19.6 -> 15.5 ms on semesterbild); the state machine when several meshes share the list (teapot +5..12 %; a single
+    // Root-box test right at mesh set-up (reference build's state machine): when several meshes share the list (teapot +5..12 %; a single
     // mesh loses 5-10 %).
-    ctx->inline_steps = ctx->knob_inline_steps >= 0 ? (uint32_t)ctx->knob_inline_steps : ((ctx->variant == KERNEL_POOL || n_mesh_prims >= 2) ? 1u : 0u);
+    ctx->inline_steps = ctx->knob_inline_steps >= 0 ? (uint32_t)ctx->knob_inline_steps : (n_mesh_prims >= 2 ? 1u : 0u);
     return MI355RT_OK;
 }
 
@@ -527,8 +524,6 @@ int apply_knob(mi355rt_context* ctx, const std::string& name, int v) {
     else if (name == "inline_steps") { if (v < -1 || v > 8) return fail(MI355RT_ERR_INVALID, "knob inline_steps"); ctx->knob_inline_steps = v; }
     else if (name == "guided_mult") { if (v < 1 || v > 64) return fail(MI355RT_ERR_INVALID, "knob guided_mult"); ctx->guided_mult = (uint32_t)v; }
     else if (name == "trav_min") { if (v < 1 || v > 64) return fail(MI355RT_ERR_INVALID, "knob trav_min"); ctx->trav_min = (uint32_t)v; }
-    else if (name == "walkers") { if (v < 4 || v > 12) return fail(MI355RT_ERR_INVALID, "knob walkers"); ctx->walker_waves = (uint32_t)v; }
-    else if (name == "pool_patience") { if (v < 0 || v > 100000) return fail(MI355RT_ERR_INVALID, "knob pool_patience"); ctx->pool_patience = (uint32_t)v; }
     else if (name == "spin_idle") { if (v < 1) return fail(MI355RT_ERR_INVALID, "knob spin_idle"); ctx->spin_limit_idle = (uint32_t)v; }
     else if (name == "spin_entry") { if (v < 1) return fail(MI355RT_ERR_INVALID, "knob spin_entry"); ctx->spin_limit_entry = (uint32_t)v; }
     else if (name == "wave_times") ctx->want_wave_times = v != 0;
@@ -544,7 +539,7 @@ extern "C" {
 // Diagnostic hook (not part of the public header).  ctx != NULL: set one knob of that context (before set_scene).  ctx == NULL: a
 // process-wide default applied to every context created afterwards -- also those the one-shot calls create; name == NULL clears
 // all defaults.  Knobs: kernel (KERNEL_* of rt_device.h, -1 = automatic), guided_mult, spin_idle, spin_entry, wave_times, and for the
-// reference build's kernels inline_steps, trav_min, walkers, pool_patience.
+// reference build's state machine inline_steps, trav_min.
 int mi355rt_debug_set_knob(mi355rt_context* ctx, const char* name, int value) {
     return guard([&]() -> int {
     if (ctx) return name ? apply_knob(ctx, name, value) : fail(MI355RT_ERR_INVALID, "knob name is null");
@@ -641,57 +636,62 @@ int mi355rt_context_set_scene(mi355rt_context* ctx, const mi355rt_scene* scene, 
     // mostly sky (1.1 rays per path) has nothing to sort and lost 14 % to the queues (profiles/r03_ab_meshfree_wavefront_fuzz_scenes.txt).
     // A probe decides: the same view at 64 pixels across, 4 samples per pixel, on the lockstep kernel -- deterministic (counter RNG), a
     // fraction of a millisecond -- and the wavefront form is kept when a path traces at least PROBE_RAYS_PER_PATH rays.
+    // Both probes below render with the context's settings (and, the first, its variant) swapped for the probe's.  Whatever way they are left --
+    // a return code, a HIP failure, a C++ exception out of render_samples' host allocations -- ProbeScope puts the full-size settings back, drops
+    // the row tables of the probe size, frees the probe's device buffers and, unless the probe was committed, leaves the context WITHOUT a scene:
+    // a context that kept have_scene with 64-pixel-wide settings would render a probe-sized image into the caller's full-size buffer.
+    struct ProbeScope {
+        mi355rt_context* c; mi355rt_settings full; uint32_t variant; uint32_t* d_tmp = nullptr; unsigned long long* d_cnt = nullptr; bool committed = false;
+        ProbeScope(mi355rt_context* ctx) : c(ctx), full(ctx->settings), variant(ctx->variant) {}
+        ~ProbeScope() {
+            c->settings = full; c->rows_valid = false;
+            if (d_tmp) (void)hipFree(d_tmp);
+            if (d_cnt) (void)hipFree(d_cnt);
+            if (!committed) { c->variant = variant; c->have_scene = false; c->row_cost.clear(); }
+        }
+    };
     if (ctx->variant == KERNEL_WAVEFRONT_MESHFREE && ctx->forced_variant < 0) {
         constexpr double PROBE_RAYS_PER_PATH = 1.6;       // veach-mis with max_bounces 1 / 2 / 3 / 16: 1.00 / 1.90 / 2.20 / 2.48 rays per path, wavefront +5.5 / -4.0 / -6.5 / -10.2 %
                                                           // against lockstep (profiles/r03_probe_calibration.txt): break-even near 1.5
-        const mi355rt_settings full = ctx->settings;
-        mi355rt_settings probe = full;
-        probe.width = std::min(full.width, 64u);
-        probe.height = std::max(1u, std::min(full.height, (uint32_t)((uint64_t)probe.width * full.height / full.width)));
-        probe.samples_per_pixel = std::min(full.samples_per_pixel, 4u);
-        uint32_t* d_tmp = nullptr;
-        if (hipMalloc((void**)&d_tmp, (size_t)probe.width * probe.height * 4) != hipSuccess) { ctx->have_scene = false; return fail(MI355RT_ERR_OOM, "hipMalloc(probe)"); }
+        ProbeScope scope(ctx);
+        mi355rt_settings probe = scope.full;
+        probe.width = std::min(scope.full.width, 64u);
+        probe.height = std::max(1u, std::min(scope.full.height, (uint32_t)((uint64_t)probe.width * scope.full.height / scope.full.width)));
+        probe.samples_per_pixel = std::min(scope.full.samples_per_pixel, 4u);
+        if (hipMalloc((void**)&scope.d_tmp, (size_t)probe.width * probe.height * 4) != hipSuccess) { scope.d_tmp = nullptr; return fail(MI355RT_ERR_OOM, "hipMalloc(probe)"); }
         ctx->settings = probe; ctx->variant = KERNEL_LOCKSTEP_NOSPEC;
         mi355rt_stats st{};
-        rc = render_samples(ctx, nullptr, 0, probe.samples_per_pixel, nullptr, d_tmp, nullptr, nullptr, &st);
-        (void)hipFree(d_tmp);
-        ctx->settings = full; ctx->rows_valid = false;
-        if (rc) { ctx->have_scene = false; return rc; }
+        rc = render_samples(ctx, nullptr, 0, probe.samples_per_pixel, nullptr, scope.d_tmp, nullptr, nullptr, &st);
+        if (rc) return rc;
         ctx->variant = ((double)st.rays >= PROBE_RAYS_PER_PATH * (double)std::max<uint64_t>(st.samples, 1)) ? KERNEL_WAVEFRONT_MESHFREE : KERNEL_LOCKSTEP_NOSPEC;
+        scope.committed = true;
     }
     // Row costs for the processing order (see mi355rt_context::row_cost): the same view at <= 64 x 96 pixels, 4 samples per pixel, one small
     // launch per probe row with its own {paths, rays} counters, all enqueued back to back and read after ONE wait -- deterministic (counter
-    // RNG), a few milliseconds, and only for frames large enough for the tail of a launch to matter (or when the knob asks).
+    // RNG), a few milliseconds.  Only the diagnostic knob turns it on (measured, profiles/r04/ab_processing_order.txt: +-0.5 % on full frames --
+    // the tail of a launch is old paths that waited in thin queues, not the rows handed out last).
     ctx->row_cost.clear();
-    const uint64_t frame_samples = (uint64_t)ctx->settings.width * ctx->settings.height * ctx->settings.samples_per_pixel;
-    (void)frame_samples;
-    if (ctx->knob_row_order == 1) {                                       // measured (profiles/r04/ab_processing_order.txt): +-0.5 % on full frames -- the tail of a launch is old
-                                                                          // paths that waited in thin queues, not the rows handed out last -- so only the knob turns it on
-        const mi355rt_settings full = ctx->settings;
-        mi355rt_settings probe = full;
-        probe.width = std::min(full.width, 64u);
-        probe.height = std::min(full.height, 96u);
-        probe.samples_per_pixel = std::min(full.samples_per_pixel, 4u);
-        uint32_t* d_tmp = nullptr; unsigned long long* d_cnt = nullptr;
+    if (ctx->knob_row_order == 1) {
+        ProbeScope scope(ctx);
+        mi355rt_settings probe = scope.full;
+        probe.width = std::min(scope.full.width, 64u);
+        probe.height = std::min(scope.full.height, 96u);
+        probe.samples_per_pixel = std::min(scope.full.samples_per_pixel, 4u);
         std::vector<unsigned long long> h_cnt(STATS_WORDS * (size_t)probe.height);
-        if (hipMalloc((void**)&d_tmp, (size_t)probe.width * probe.height * 4) != hipSuccess || hipMalloc((void**)&d_cnt, h_cnt.size() * 8) != hipSuccess ||
-            hipMemset(d_cnt, 0, h_cnt.size() * 8) != hipSuccess) {
-            if (d_tmp) (void)hipFree(d_tmp);
-            if (d_cnt) (void)hipFree(d_cnt);
-            ctx->have_scene = false; return fail(MI355RT_ERR_OOM, "hipMalloc(row probe)");
-        }
+        if (hipMalloc((void**)&scope.d_tmp, (size_t)probe.width * probe.height * 4) != hipSuccess) { scope.d_tmp = nullptr; return fail(MI355RT_ERR_OOM, "hipMalloc(row probe)"); }
+        if (hipMalloc((void**)&scope.d_cnt, h_cnt.size() * 8) != hipSuccess) { scope.d_cnt = nullptr; return fail(MI355RT_ERR_OOM, "hipMalloc(row probe)"); }
+        HIP_TRY(hipMemset(scope.d_cnt, 0, h_cnt.size() * 8));
         ctx->settings = probe;
-        rc = render_samples(ctx, nullptr, 0, probe.samples_per_pixel, nullptr, d_tmp, nullptr, nullptr, nullptr, d_cnt);
-        if (!rc && hipMemcpy(h_cnt.data(), d_cnt, h_cnt.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MI355RT_ERR_HIP, "row probe: copy back");   // (waits for the launches)
-        if (!rc) rc = report_device_error(ctx);
-        (void)hipFree(d_tmp); (void)hipFree(d_cnt);
-        ctx->settings = full; ctx->rows_valid = false;
-        if (rc) { ctx->have_scene = false; return rc; }
-        ctx->row_cost.resize(full.height);
-        for (uint32_t y = 0; y < full.height; ++y) {
-            const uint32_t i = (uint32_t)std::min<uint64_t>(probe.height - 1, (uint64_t)y * probe.height / full.height);
+        rc = render_samples(ctx, nullptr, 0, probe.samples_per_pixel, nullptr, scope.d_tmp, nullptr, nullptr, nullptr, scope.d_cnt);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(h_cnt.data(), scope.d_cnt, h_cnt.size() * 8, hipMemcpyDeviceToHost));                    // (waits for the launches)
+        if ((rc = report_device_error(ctx))) return rc;
+        ctx->row_cost.resize(scope.full.height);
+        for (uint32_t y = 0; y < scope.full.height; ++y) {
+            const uint32_t i = (uint32_t)std::min<uint64_t>(probe.height - 1, (uint64_t)y * probe.height / scope.full.height);
             ctx->row_cost[y] = (float)((double)h_cnt[STATS_WORDS * (size_t)i + 1] / (double)std::max<unsigned long long>(h_cnt[STATS_WORDS * (size_t)i], 1ull));
         }
+        scope.committed = true;
     }
     return MI355RT_OK;
     });
@@ -733,10 +733,9 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
     if (fixed_aabb && rng_mode != MI355RT_RNG_CTR) return fail(MI355RT_ERR_INVALID, "MI355RT_FLAG_FIXED_AABB needs MI355RT_RNG_CTR (the replay mode reproduces the reference as it is)");
     uint32_t variant = ctx->variant;
     if (fixed_aabb && ctx->has_mesh) {                                // without a mesh the flag changes nothing
-        variant = ctx->variant == KERNEL_POOL ? (uint32_t)KERNEL_POOL_FIXAABB : ctx->variant == KERNEL_STATE_MACHINE ? (uint32_t)KERNEL_STATE_MACHINE_FIXAABB : (uint32_t)KERNEL_WAVEFRONT_FIXAABB;
+        variant = ctx->variant == KERNEL_STATE_MACHINE ? (uint32_t)KERNEL_STATE_MACHINE_FIXAABB : (uint32_t)KERNEL_WAVEFRONT_FIXAABB;
         if (!render_ctr_variant_built(variant)) variant = KERNEL_WAVEFRONT_FIXAABB;
     }
-    const bool pool = variant == KERNEL_POOL || variant == KERNEL_POOL_FIXAABB;
     const uint64_t seed = opt ? opt->seed : 0;
     const uint32_t n_rows = (uint32_t)ctx->rows_host.size();
     if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs[variant]; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }
@@ -790,7 +789,8 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         // halve the band and try again: more, smaller bands give the same image (tiling invariance), just more launches.
         for (;;) {
             rc = ctx->radiance.ensure((size_t)(band_pixels_max * spp * 3));
-            if (rc != MI355RT_ERR_OOM || band_pixels_max <= 1) break;
+            // (the row probe's counter blocks are laid out one per ROW = per band: halving would make more bands than blocks -- it returns the OOM)
+            if (rc != MI355RT_ERR_OOM || band_pixels_max <= 1 || d_row_counters) break;
             (void)hipGetLastError();
             band_pixels_max = (band_pixels_max + 1) / 2;
         }
@@ -812,8 +812,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.sample0 = s0;
         magic_div((uint32_t)spp, p.spp_mul, p.spp_shift); magic_div(st.width, p.width_mul, p.width_shift);
         p.trav_min = ctx->trav_min; p.inline_steps = ctx->inline_steps;
-        p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, pool ? POOL_NODE_CAP : LDS_NODE_CAP);    // (the wavefront kernel clamps to its own WF_LDS_NODES)
-        p.walker_waves = ctx->walker_waves; p.pool_patience = ctx->pool_patience;
+        p.lds_nodes = (uint32_t)std::min<size_t>(ctx->n_nodes, LDS_NODE_CAP);    // (the wavefront kernel clamps to its own WF_LDS_NODES)
         p.err = ctx->errword.p; p.spin_limit_idle = ctx->spin_limit_idle; p.spin_limit_entry = ctx->spin_limit_entry;
         ResolveParams r{};
         r.radiance = ctx->radiance.p; r.out_packed = (uint32_t*)d_out_packed; r.out_linear = (float*)d_out_linear;
@@ -836,8 +835,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
             const uint32_t waves_per_block = block_threads / 64;
             const uint32_t min_runs = (p.band_samples + run_min - 1) / run_min;               // never more waves than minimum-size runs
             const uint32_t grid = std::max(1u, std::min(resident, (min_runs + waves_per_block - 1) / waves_per_block));
-            const uint32_t claiming_waves = pool ? waves_per_block - ctx->walker_waves : waves_per_block;   // (the wavefront kernel: every wave claims)     // walker waves never claim samples
-            p.guided_div = std::max(1u, ctx->guided_mult * grid * claiming_waves / WORK_SHARDS);
+            p.guided_div = std::max(1u, ctx->guided_mult * grid * waves_per_block / WORK_SHARDS);
             p.wave_times = nullptr;
             if (ctx->want_wave_times) {
                 ctx->wave_times_n = grid * waves_per_block;

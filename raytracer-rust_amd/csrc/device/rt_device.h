@@ -56,7 +56,6 @@ constexpr uint32_t NODE_MAX_LEAF = 63;                           // triangles pe
 // LDS copy of the hot top of the node array in the state-machine kernel: one 1024-thread workgroup per CU owns the
 // CU's whole 160 KiB (163 840 B); 5 104 nodes x 32 B = 163 328 B.
 constexpr uint32_t LDS_NODE_CAP = 5104;
-constexpr uint32_t POOL_NODE_CAP = 3548;        // pool kernel: 50 KB of its LDS hold the walk requests / results / ring (rt_kernels.hip)
 
 struct DevTri { float v0[3], e1[3], e2[3], n[3]; };
 static_assert(sizeof(DevTri) == 48, "DevTri");
@@ -117,15 +116,12 @@ struct RenderParams {
     uint32_t trav_min;           // state-machine kernel: run BVH rounds while at least this many lanes are walking
     uint32_t inline_steps;       // state-machine kernel: box tests taken right at mesh setup (short walks skip the TRAV round trip)
     uint32_t lds_nodes;          // state-machine kernel: nodes [0, lds_nodes) are read from the workgroup's LDS copy (<= LDS_NODE_CAP)
-    uint32_t walker_waves;       // pool kernel: waves of each workgroup that only walk (4 .. 12 of 16)
-    uint32_t pool_patience;      // pool kernel: polls a producer waits for more results before it runs an under-filled pass
-    uint32_t spin_limit_idle;    // wavefront / pool kernels: polls without progress before a wave gives up (SPIN_LIMIT_IDLE; a diagnostic hook lowers it)
+    uint32_t spin_limit_idle;    // wavefront kernel: polls without progress before a wave gives up (SPIN_LIMIT_IDLE; a diagnostic hook lowers it)
     uint32_t spin_limit_entry;   // wavefront kernel: polls of one ring entry before a lane gives up (SPIN_LIMIT_ENTRY)
 };
 // The bounded waits a kernel can give up (RenderParams.err): an idle wave of the wavefront kernel that saw no progress in its workgroup; a lane
-// whose ring entry was never written (pop) or never emptied (push); a wave that left because another wave of its workgroup had given up;
-// (reference build) a producer of the walk pool whose walk results did not come back; a walker of the pool that saw neither requests nor progress.
-enum : uint32_t { WAIT_WF_IDLE = 1u, WAIT_WF_RING = 2u, WAIT_WF_FOLLOWED = 4u, WAIT_POOL_RESULTS = 8u, WAIT_POOL_WALKER_IDLE = 16u };
+// whose ring entry was never written (pop) or never emptied (push); a wave that left because another wave of its workgroup had given up.
+enum : uint32_t { WAIT_WF_IDLE = 1u, WAIT_WF_RING = 2u, WAIT_WF_FOLLOWED = 4u };
 constexpr uint32_t SPIN_LIMIT_IDLE = 1u << 22;    // watchdog bounds: seconds of polling, never reached by a healthy launch
 constexpr uint32_t SPIN_LIMIT_ENTRY = 1u << 20;
 
@@ -136,8 +132,8 @@ enum : uint32_t {
     KERNEL_STATE_MACHINE = 2,    // wave-voted TRAV / TOP / SHADE blocks (scenes with meshes)
     KERNEL_LOCKSTEP_SIMPLE = 3,  // KERNEL_LOCKSTEP for scenes whose materials are only Lambertian (solid) / Emissive / Null
     KERNEL_STATE_MACHINE_FIXAABB = 4,   // KERNEL_STATE_MACHINE with the opt-in slab test (MI355RT_FLAG_FIXED_AABB)
-    KERNEL_POOL = 5,             // state machine whose BVH walks are served by dedicated walker waves through LDS (scenes with meshes)
-    KERNEL_POOL_FIXAABB = 6,
+    KERNEL_RETIRED_5 = 5,        // (round 2's LDS walk pool and its fixed-AABB form; removed in round 5, numbers kept so that the others stay what
+    KERNEL_RETIRED_6 = 6,        //  logs and tests of earlier rounds call them; no library holds them)
     KERNEL_WAVEFRONT = 7,        // path state in LDS, stages as queues: every pass runs with (nearly) full lanes (scenes with meshes)
     KERNEL_WAVEFRONT_FIXAABB = 8,
     KERNEL_LOCKSTEP_NOSPEC = 9,  // KERNEL_LOCKSTEP without the metal and dielectric branches: 72 VGPRs = 7 waves per SIMD (veach-mis)
@@ -245,7 +241,7 @@ inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT 
 constexpr uint32_t BLOCK_THREADS_WF_MESHFREE = MI355RT_WF_THREADS_MESHFREE;
 inline uint32_t block_threads_of(uint32_t variant) {
     return variant == KERNEL_WAVEFRONT_MESHFREE ? BLOCK_THREADS_WF_MESHFREE : is_wavefront(variant) ? BLOCK_THREADS_WF
-         : (variant == KERNEL_STATE_MACHINE || variant == KERNEL_STATE_MACHINE_FIXAABB || variant == KERNEL_POOL || variant == KERNEL_POOL_FIXAABB) ? BLOCK_THREADS_SM : BLOCK_THREADS;
+         : (variant == KERNEL_STATE_MACHINE || variant == KERNEL_STATE_MACHINE_FIXAABB) ? BLOCK_THREADS_SM : BLOCK_THREADS;
 }
 
 }  // namespace mi355rt

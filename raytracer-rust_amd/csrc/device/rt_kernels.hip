@@ -23,7 +23,7 @@
 //
 // Files (one translation unit; this file includes the rest): rt_math.h (vec3.rs helpers), rt_rng.h (Philox / ChaCha12 replay),
 // rt_intersect.h (hit tests, BVH walk, finish_hit), rt_materials.h (scatter, camera, miss colour), here: the work cursor,
-// shade_and_regenerate() and the lockstep kernels, then rt_mesh_variants.h (state machine, walk pool), rt_wavefront.h
+// shade_and_regenerate() and the lockstep kernels, then rt_mesh_variants.h (the state machine of the reference build), rt_wavefront.h
 // (k_render_ctr_wf), and at the end k_resolve, k_render_ref, the debug kernels and the launchers.
 //
 // Numerics: compiled with -ffp-contract=off and correctly rounded f32 divide/sqrt; every expression
@@ -134,15 +134,23 @@ struct PathState {
 // Must be called in wave-uniform control flow.
 DI int lane_shfl(int v, uint32_t src_lane) { return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), v); }
 DI float lane_shfl(float v, uint32_t src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v))); }
-template <bool WIDE = false, bool TRY1 = false>
+template <bool WIDE = false, int TRY1 = 0>
 DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane, const uint32_t* b1 = nullptr) {
     f3 p = mk(u32_to_range11(rng.b0[1]), u32_to_range11(rng.b0[2]), u32_to_range11(rng.b0[3]));   // try 0
     bool need = diffuse && !(len2(p) < 1.0f);
     uint32_t jbase = 1;
-    if constexpr (TRY1) {                                                          // try 1 was drawn in the lane itself, next to the event's block
+    if constexpr (TRY1 >= 1) {                                                     // try 1 was drawn in the lane itself, next to the event's block
         const f3 p1 = mk(u32_to_range11(b1[1]), u32_to_range11(b1[2]), u32_to_range11(b1[3]));
         if (need && len2(p1) < 1.0f) { p = p1; need = false; }
         jbase = 2;                                                                 // (tries 1 AND 2 in the lane: the same kernel spills, 14.8 -> 17.9 ms)
+    }
+    if constexpr (TRY1 >= 2) {
+        if (__ballot(need) != 0ull) {
+            uint32_t b2[4]; RngCtr::block<WIDE>(rng.w, 2u, b2);
+            const f3 p2 = mk(u32_to_range11(b2[1]), u32_to_range11(b2[2]), u32_to_range11(b2[3]));
+            if (need && len2(p2) < 1.0f) { p = p2; need = false; }
+        }
+        jbase = 3;
     }
     for (;;) {
         const uint64_t m = __ballot(need);
@@ -155,11 +163,12 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane, cons
         const uint32_t orank = lane >> lg;
         const bool worker = orank < n;
         const uint32_t olane = (uint32_t)lane_shfl(tab, worker ? orank : 0u);
-        const uint32_t ok0 = (uint32_t)lane_shfl((int)rng.k0, olane), ok1 = (uint32_t)lane_shfl((int)rng.k1, olane);
-        const uint32_t ox = (uint32_t)lane_shfl((int)rng.x, olane), os = (uint32_t)lane_shfl((int)rng.s, olane);
-        const uint32_t oray = (uint32_t)lane_shfl((int)rng.ray, olane), oj = (uint32_t)lane_shfl((int)jbase, olane);
+        uint32_t ow[RngCtr::NW];                                                   // the owner's draw address (rt_rng.h)
+#pragma unroll
+        for (int i = 0; i < RngCtr::NW; ++i) ow[i] = (uint32_t)lane_shfl((int)rng.w[i], olane);
+        const uint32_t oj = (uint32_t)lane_shfl((int)jbase, olane);
         uint32_t w[4];
-        philox4x32_10<WIDE>(ok0, ok1, ox, os, oray, oj + (lane & ((1u << lg) - 1u)), w);
+        RngCtr::block<WIDE>(ow, oj + (lane & ((1u << lg) - 1u)), w);
         const f3 q = mk(u32_to_range11(w[1]), u32_to_range11(w[2]), u32_to_range11(w[3]));
         const uint64_t acc = __ballot(worker && (len2(q) < 1.0f));
         const uint32_t seg_lo = r << lg;                                           // my segment of the ballot (owners only)
@@ -182,13 +191,13 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane, cons
 // Returns false when no lane is live afterwards and no work is left to deal.
 // DEFAULTS: give the per-lane temporaries default values.  The lockstep kernels run without (every value is read only on the
 // path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %), and since round 3 so does the wavefront
-// kernel (rt_wavefront.h, MI355RT_AB_WF_DEFAULTS); the reference build's state-machine / pool kernels keep them (their other lanes'
+// kernel (rt_wavefront.h, MI355RT_AB_WF_DEFAULTS); the reference build's state machine keeps them (its other lanes'
 // state must not be touched).  WIDE: Philox on 64-bit products (rt_rng.h).  DROP_PRIO: lower the wave's priority to 0 once the
 // fresh samples are dealt (the caller raised it for the memory-bound half of the iteration).  Q0_IN_HIT: see struct Hit.
 // FASTN: see normalized() (rt_math.h).  TRY1: try 1 of the unit-ball draw comes from a second Philox block drawn in the lane itself, right after the
 // event's block, so the cooperative rounds start at try 2 and a second round is needed in 44 % of the iterations instead of all: cornell -0.9 %
 // on the Lambert-only kernel; every other kernel pays for the three more live registers with spills (+1.5 ... +23 %: profiles/r03_ab_inlane_try1.txt).
-template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, bool FASTN = false, bool TRY1 = false, class WC>
+template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, bool FASTN = false, int TRY1 = 0, class WC>
 DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
@@ -259,7 +268,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
         if (!fresh) ps.rng.next_event();
         ps.rng.template load_block0<WIDE>();
         uint32_t blk1[4] = {0u, 0u, 0u, 0u};
-        if constexpr (TRY1) philox4x32_10<WIDE>(ps.rng.k0, ps.rng.k1, ps.rng.x, ps.rng.s, ps.rng.ray, 1u, blk1);
+        if constexpr (TRY1 >= 1) RngCtr::block<WIDE>(ps.rng.w, 1u, blk1);
         if (live) {
             if (fresh) {
                 // (FASTN: div_bounded with the host's RN(1/width) -- the dividend is 0 or in [2^-24, 2^24), the divisor an image dimension in [1, 2^24);
@@ -340,7 +349,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
 #define MI355RT_AB_FASTN_LS true
 #endif
 #ifndef MI355RT_AB_TRY1_SIMPLE
-#define MI355RT_AB_TRY1_SIMPLE true
+#define MI355RT_AB_TRY1_SIMPLE 1
 #endif
 template <bool HAS_MESH, uint32_t MATS>
 DI void render_ctr_lockstep(const RenderParams& P) {
@@ -349,7 +358,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
     const uint32_t lane = threadIdx.x & 63u;
     WorkCursor wc; wc.init();
     PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
-    ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
+    ps.rng.clear();
     bool live = false;
     uint32_t n_paths = 0, n_rays = 0;
     Prof prof; prof.begin();
@@ -367,7 +376,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         __builtin_amdgcn_s_setprio(1);
         if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, MI355RT_AB_FASTN_LS, SIMPLE && MI355RT_AB_TRY1_SIMPLE>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, MI355RT_AB_FASTN_LS, SIMPLE ? MI355RT_AB_TRY1_SIMPLE : 0>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths
@@ -407,12 +416,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per
 
 }  // namespace mi355rt
 
-// The two earlier generations of the mesh path -- the in-wave state machine and the LDS walk pool -- are retired from the product
-// library: they are compiled only into the tests' reference build (-DMI355RT_REFS, build.build_device_variant("refs")), where they
-// serve as bit-identity references for the wavefront kernel.  k_render_ctr_mesh above stays in the product library: the plain
+// Round 1's form of the mesh path -- the in-wave state machine -- is retired from the product library: it is compiled only into the
+// tests' reference build (-DMI355RT_REFS, build.build_device_variant("refs")), where it serves as a bit-identity reference for the
+// wavefront kernel.  k_render_ctr_mesh above stays in the product library: the plain
 // per-lane loop is the simplest statement of the BVH walk and what the diagnostic knob "kernel" = 1 selects.
 #ifdef MI355RT_REFS
-#include "rt_mesh_variants.h"   // k_render_ctr_sm, k_render_ctr_pool (use the shared pieces above)
+#include "rt_mesh_variants.h"   // k_render_ctr_sm (uses the shared pieces above)
 #endif
 #include "rt_wavefront.h"       // k_render_ctr_wf
 
@@ -523,7 +532,7 @@ __global__ void __launch_bounds__(64) k_debug_scatter(const DevMat* __restrict__
     const DebugScatterIn r = in[i];
     Hit h; h.t = 0.f; h.p = mk(r.p[0], r.p[1], r.p[2]); h.n = mk(r.n[0], r.n[1], r.n[2]);
     h.mat_ff = r.material | (r.front_face ? 0x80000000u : 0u);
-    RngCtr rng; rng.start(r.k0, r.k1, r.x, r.s); rng.ray = r.ray; rng.load_block0();
+    RngCtr rng; rng.start(r.k0, r.k1, r.x, r.s); rng.set_ray(r.ray); rng.load_block0();
     const float4 q0 = reinterpret_cast<const float4*>(mats + r.material)[0];
     f3 no = mk(0, 0, 0), nd = mk(0, 0, 0), atten = mk(0, 0, 0), emitted = mk(0, 0, 0);
     const bool ok = surface_scatter(mats, texs, q0, h, mk(r.rd[0], r.rd[1], r.rd[2]), rng, no, nd, atten, emitted);
@@ -573,8 +582,6 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
         case KERNEL_WAVEFRONT:       hipLaunchKernelGGL(k_render_ctr_wf, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_FIXAABB: hipLaunchKernelGGL(k_render_ctr_wf_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
 #ifdef MI355RT_REFS
-        case KERNEL_POOL:            hipLaunchKernelGGL(k_render_ctr_pool, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
-        case KERNEL_POOL_FIXAABB:    hipLaunchKernelGGL(k_render_ctr_pool_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
         case KERNEL_STATE_MACHINE_FIXAABB: hipLaunchKernelGGL(k_render_ctr_sm_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
         case KERNEL_STATE_MACHINE:   hipLaunchKernelGGL(k_render_ctr_sm, dim3(grid_blocks), dim3(BLOCK_THREADS_SM), 0, (hipStream_t)stream, p); break;
 #endif
@@ -584,7 +591,7 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
 }
 bool render_ctr_variant_built(uint32_t variant) {
 #ifdef MI355RT_REFS
-    return variant < KERNEL_VARIANTS;
+    return variant < KERNEL_VARIANTS && variant != KERNEL_RETIRED_5 && variant != KERNEL_RETIRED_6;
 #else
     return variant == KERNEL_LOCKSTEP || variant == KERNEL_LOCKSTEP_MESH || variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_LOCKSTEP_NOSPEC ||
            is_wavefront(variant);
@@ -611,8 +618,6 @@ int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs,
                    : variant == KERNEL_WAVEFRONT ? reinterpret_cast<const void*>(k_render_ctr_wf)
 #ifdef MI355RT_REFS
                    : variant == KERNEL_STATE_MACHINE_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_sm_fixaabb)
-                   : variant == KERNEL_POOL ? reinterpret_cast<const void*>(k_render_ctr_pool)
-                   : variant == KERNEL_POOL_FIXAABB ? reinterpret_cast<const void*>(k_render_ctr_pool_fixaabb)
                    : variant == KERNEL_STATE_MACHINE ? reinterpret_cast<const void*>(k_render_ctr_sm)
 #endif
                                                        : reinterpret_cast<const void*>(k_render_ctr_wf_fixaabb);

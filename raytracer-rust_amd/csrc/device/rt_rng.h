@@ -21,17 +21,15 @@ DI float u32_to_range11(uint32_t w) {
 #endif
 }
 
-// Philox4x32-10: counter-based, no state.  10 x (2 x 32x32->64 multiplies + 4 xor + 2 add).
+// Philox4x32-R (Salmon et al., SC'11): counter-based, no state.  R x (2 x 32x32->64 multiplies + 4 xor + 2 add).
 // WIDE: one 64-bit product per multiplier -- v_mad_u64_u32 issues like ONE v_mul_hi_u32 (2.1 add slots, tools/microbench/int_mul.hip)
 // and yields both halves, where __umulhi() and `*` written separately compile to two such instructions: 20 instead of 40
-// slow multiplies per call.  The VALU-bound lockstep kernels use it (cornell -6.1 %, veach-mis -2.4 %); the wavefront kernel
-// was 2-3 % faster on the two independent multiplies while its SHADE spilled 50 registers (round 2) and is 1 % faster on the wide
-// form since round 3 (rt_wavefront.h).  Same bits either way.
-template <bool WIDE = false>
-DI void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
+// slow multiplies per call.  Same bits either way.
+template <bool WIDE = false, int ROUNDS = 10>
+DI void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         uint32_t hi0, lo0, hi1, lo1;
         if (WIDE) {
             const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
@@ -46,17 +44,50 @@ DI void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// pcg4d (Jarzynski & Olano, "Hash Functions for GPU Rendering", JCGT 9(3), 2020): a bijection of 128 bits -- one LCG step per word, a
+// round of word-by-word multiply-adds, xorshift 16, a second round.  12 multiply-adds (a*b+c on 32-bit operands: one v_mad_u64_u32 each,
+// the low half is what is used) + 8 shift / xor: about 32 issue slots where Philox4x32-10 takes about 85.
+DI uint32_t mad32(uint32_t a, uint32_t b, uint32_t c) { return (uint32_t)((uint64_t)a * b + c); }
+DI void pcg4d(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t (&out)[4]) {
+    x = mad32(x, 1664525u, 1013904223u); y = mad32(y, 1664525u, 1013904223u); z = mad32(z, 1664525u, 1013904223u); w = mad32(w, 1664525u, 1013904223u);
+    x = mad32(y, w, x); y = mad32(z, x, y); z = mad32(x, y, z); w = mad32(y, z, w);
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    x = mad32(y, w, x); y = mad32(z, x, y); z = mad32(x, y, z); w = mad32(y, z, w);
+    out[0] = x; out[1] = y; out[2] = z; out[3] = w;
+}
+
+// Which counter-mode generator the library is built with (the oracle's CTR mode mirrors it: oracle/rt_oracle.cpp, CTR_GEN):
+//   0  Philox4x32-10, key = row key (64 bit), counter = (x, sample, ray, block)                      -- rounds 1-4
+//   1  Philox4x32-7, same addressing (Random123's Crush-resistant minimum)
+//   2  pcg4d: a per-path base = pcg4d(x, sample, key lo, key hi); block j of the event after ray r = pcg4d(base + (0, 0, r, j))
+#ifndef MI355RT_CTR_GEN
+#define MI355RT_CTR_GEN 0
+#endif
+constexpr int CTR_GEN = MI355RT_CTR_GEN;
+
 // Counter mode sampler: draws are addressed, not consumed (slots documented in oracle/rt_oracle.cpp
 // and DESIGN.md): jitter = (ray 0, block 0, words 0/1); scatter event after ray r uses ray r+1:
 // random::<f32>() number k -> block 0 word k; rejection try j -> block j words 1..3.
+// `w` = what addresses a path's draws (NW words; the cooperative rejection hands exactly these to its worker lanes):
+//   Philox: k0, k1, x, s, ray;  pcg4d: base.x, base.y, base.z + ray, base.w.
 struct RngCtr {
-    uint32_t k0, k1, x, s, ray;
+    static constexpr int NW = CTR_GEN == 2 ? 4 : 5;
+    uint32_t w[NW];
     uint32_t b0[4];
-    // One Philox call per loop iteration serves BOTH kinds of lanes: a freshly dealt path reads its camera
+    template <bool WIDE = false> DI static void block(const uint32_t (&a)[NW], uint32_t j, uint32_t (&out)[4]) {
+        if constexpr (CTR_GEN == 2) pcg4d(a[0], a[1], a[2], a[3] + j, out);
+        else philox4x32<WIDE, CTR_GEN == 1 ? 7 : 10>(a[0], a[1], a[2], a[3], a[NW - 1], j, out);
+    }
+    DI void clear() { for (int i = 0; i < NW; ++i) w[i] = 0u; b0[0] = b0[1] = b0[2] = b0[3] = 0u; }
+    // One generator call per loop iteration serves BOTH kinds of lanes: a freshly dealt path reads its camera
     // jitter from (ray 0, block 0); a continuing path reads its scatter draws from (ray r+1, block 0).
-    DI void start(uint32_t k0_, uint32_t k1_, uint32_t x_, uint32_t s_) { k0 = k0_; k1 = k1_; x = x_; s = s_; ray = 0; }
-    DI void next_event() { ++ray; }
-    template <bool WIDE = false> DI void load_block0() { philox4x32_10<WIDE>(k0, k1, x, s, ray, 0u, b0); }
+    DI void start(uint32_t k0_, uint32_t k1_, uint32_t x_, uint32_t s_) {
+        if constexpr (CTR_GEN == 2) { uint32_t b[4]; pcg4d(x_, s_, k0_, k1_, b); w[0] = b[0]; w[1] = b[1]; w[2] = b[2]; w[3] = b[3]; }
+        else { w[0] = k0_; w[1] = k1_; w[2] = x_; w[3] = s_; w[NW - 1] = 0u; }
+    }
+    DI void set_ray(uint32_t r) { if constexpr (CTR_GEN == 2) w[2] += r; else w[NW - 1] = r; }     // right after start(): the path is at ray r
+    DI void next_event() { if constexpr (CTR_GEN == 2) ++w[2]; else ++w[NW - 1]; }
+    template <bool WIDE = false> DI void load_block0() { block<WIDE>(w, 0u, b0); }
     DI float jitter_u() { return u32_to_f01(b0[0]); }
     DI float jitter_v() { return u32_to_f01(b0[1]); }
     DI void begin_scatter() {}
@@ -64,7 +95,7 @@ struct RngCtr {
     DI float uniform01_1() { return u32_to_f01(b0[1]); }
     template <bool WIDE = false> DI f3 cube_point(uint32_t j) {
         if (j == 0) return mk(u32_to_range11(b0[1]), u32_to_range11(b0[2]), u32_to_range11(b0[3]));
-        uint32_t b[4]; philox4x32_10<WIDE>(k0, k1, x, s, ray, j, b);
+        uint32_t b[4]; block<WIDE>(w, j, b);
         return mk(u32_to_range11(b[1]), u32_to_range11(b[2]), u32_to_range11(b[3]));
     }
 };

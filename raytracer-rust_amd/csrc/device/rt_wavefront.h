@@ -44,7 +44,7 @@ namespace mi355rt {
 // ===================================================================================================
 // k_render_ctr_wf -- the path tracer as a WAVEFRONT inside one workgroup: path state lives in LDS, stages are queues.
 //
-// The state machine and the pool kernel keep a path in the registers of ONE lane for its whole life, so every pass of every
+// The lockstep loop and the state machine keep a path in the registers of ONE lane for its whole life, so every pass of every
 // stage runs with whatever lanes of that wave happen to be in that stage (measured: 0.40 of the lanes on semesterbild).  Here
 // the CU's workgroup owns WF_PATHS path slots in LDS (20 dwords each) and queues of slot numbers -- FREE, WALK (a BVH walk in
 // progress), TOP1 (a ray whose walk is back), SHADE x 4 material classes.  Every wave loops: look at the queue lengths, choose a
@@ -471,12 +471,12 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             // (the defaults stay: with the path state and the record left uninitialised for the lanes that hold no slot the same
             // kernel ran 50 % slower -- 41.5 instead of 27.9 ms on semesterbild)
             PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
-            ps.rng.k0 = ps.rng.k1 = ps.rng.x = ps.rng.s = ps.rng.ray = 0; ps.rng.b0[0] = ps.rng.b0[1] = ps.rng.b0[2] = ps.rng.b0[3] = 0;
+            ps.rng.clear();
             Cand c; cand_reset(c);
             if (have) {
                 Slot::load_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index, c);
                 start_path(P, ps.sidx, ps.rng, ps.px, ps.py);                   // the RNG key is a function of the sample index
-                ps.rng.ray = ps.ray_index;
+                ps.rng.set_ray(ps.ray_index);
             }
             bool live = have;
             const bool any_hit = have && c.idx != CAND_NONE;

@@ -147,26 +147,25 @@ int bvh_build_threads(const mi355rt_triangle* tris, uint32_t n, std::vector<mi35
 extern "C" int mi355rt_bvh_build_threads(const mi355rt_triangle* triangles, uint32_t n_triangles, int n_threads, mi355rt_bvh_node* out_nodes,
                                          uint32_t* out_indices, uint32_t* out_n_nodes, uint32_t* out_max_depth) {
     using namespace mi355rt_host;
+    return mi355rt_host::guard("bvh_build", MI355RT_ERR_INVALID, [&]() -> int {     // nothing is thrown across the C ABI (host_common.hpp)
     std::vector<mi355rt_bvh_node> nodes; std::vector<uint32_t> indices; uint32_t md = 0;
-    int rc;
-    try { rc = bvh_build_threads(triangles, n_triangles, nodes, indices, md, n_threads); }
-    catch (const std::exception& e) { return set_error(MI355RT_ERR_OOM, std::string("bvh_build: ") + e.what()); }
+    const int rc = bvh_build_threads(triangles, n_triangles, nodes, indices, md, n_threads);
     if (rc) return rc;
     if (out_nodes) std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(mi355rt_bvh_node));
     if (out_indices) std::memcpy(out_indices, indices.data(), indices.size() * sizeof(uint32_t));
     if (out_n_nodes) *out_n_nodes = (uint32_t)nodes.size();
     if (out_max_depth) *out_max_depth = md;
     return MI355RT_OK;
+    });
 }
 
 extern "C" int mi355rt_bvh_build(const mi355rt_triangle* triangles, uint32_t n_triangles, mi355rt_bvh_node* out_nodes,
                                  uint32_t* inout_n_nodes, uint32_t* out_indices, uint32_t* inout_n_indices, uint32_t* out_max_depth) {
     using namespace mi355rt_host;
+    return mi355rt_host::guard("bvh_build", MI355RT_ERR_INVALID, [&]() -> int {     // nothing is thrown across the C ABI (host_common.hpp)
     if (!inout_n_nodes || !inout_n_indices) return set_error(MI355RT_ERR_INVALID, "bvh_build: count pointers are null");
     std::vector<mi355rt_bvh_node> nodes; std::vector<uint32_t> indices; uint32_t md = 0;
-    int rc;
-    try { rc = bvh_build(triangles, n_triangles, nodes, indices, md); }
-    catch (const std::exception& e) { return set_error(MI355RT_ERR_OOM, std::string("bvh_build: ") + e.what()); }   // nothing is thrown across the C ABI
+    const int rc = bvh_build(triangles, n_triangles, nodes, indices, md);
     if (rc) return rc;
     if (out_nodes || out_indices) {
         if (!out_nodes || !out_indices || *inout_n_nodes < nodes.size() || *inout_n_indices < indices.size())
@@ -177,4 +176,5 @@ extern "C" int mi355rt_bvh_build(const mi355rt_triangle* triangles, uint32_t n_t
     *inout_n_nodes = (uint32_t)nodes.size(); *inout_n_indices = (uint32_t)indices.size();
     if (out_max_depth) *out_max_depth = md;
     return MI355RT_OK;
+    });
 }

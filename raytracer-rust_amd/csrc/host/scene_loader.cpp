@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include <memory>
 #include "host_common.hpp"
 #include "json.hpp"
 #include "mesh_io.hpp"
@@ -372,20 +373,26 @@ void load_impl(const std::string& json_path, const mi355rt_load_overrides* ov, m
 extern "C" {
 
 int mi355rt_scene_load_json(const char* json_path, const mi355rt_load_overrides* overrides, mi355rt_loaded_scene** out_scene) {
+    // The barrier of host_common.hpp around everything: bad_alloc -> MI355RT_ERR_OOM without allocating a message, anything else -> _IO.  The
+    // handlers inside build their messages with std::string, which may throw again under the same shortage -- that, too, ends in the barrier.
+    return mi355rt_host::guard("scene_load_json", MI355RT_ERR_IO, [&]() -> int {
     if (!json_path || !out_scene) return set_error(MI355RT_ERR_INVALID, "scene_load_json: null argument");
-    auto* s = new (std::nothrow) mi355rt_loaded_scene();
+    std::unique_ptr<mi355rt_loaded_scene> s(new (std::nothrow) mi355rt_loaded_scene());      // (freed on every path out, exceptions included)
     if (!s) return set_error(MI355RT_ERR_OOM, "host allocation failed");
     try {
         load_impl(json_path, overrides, *s);
     } catch (const ParseError& e) {
-        delete s;
         return set_error(MI355RT_ERR_IO, std::string("Failed to load scene '") + json_path + "': " + e.msg);
+    } catch (const std::bad_alloc&) {
+        throw;                                                                               // -> MI355RT_ERR_OOM in the barrier
+    } catch (const std::length_error&) {
+        throw;
     } catch (const std::exception& e) {
-        delete s;
         return set_error(MI355RT_ERR_IO, std::string("Failed to load scene '") + json_path + "': " + e.what());
     }
-    *out_scene = s;
+    *out_scene = s.release();
     return MI355RT_OK;
+    });
 }
 void mi355rt_scene_free(mi355rt_loaded_scene* s) { delete s; }
 const mi355rt_scene* mi355rt_loaded_scene_get(const mi355rt_loaded_scene* s) { return s ? &s->scene : nullptr; }

@@ -28,7 +28,7 @@ def load(so):
 
 
 def refs():
-    """The tests' reference build: the product sources plus the retired mesh kernels (state machine, walk pool), -DMI355RT_REFS."""
+    """The tests' reference build: the product sources plus the retired mesh kernel (the state machine), -DMI355RT_REFS."""
     return load(build.build_device_variant("refs", ["MI355RT_REFS"]))
 
 
@@ -94,7 +94,7 @@ def _check(rc, what, library=None):
 
 def set_knob(name, value, library=None):
     """Diagnostic: process-wide default knob for every context created afterwards (also inside the one-shot calls).
-    Knobs: kernel, guided_mult, spin_idle, spin_entry, wave_times, row_order, inline_steps, trav_min, walkers, pool_patience (rt_api.cpp)."""
+    Knobs: kernel, guided_mult, spin_idle, spin_entry, wave_times, row_order, inline_steps, trav_min (rt_api.cpp)."""
     L = library or lib()
     _check(L.mi355rt_debug_set_knob(None, name.encode(), int(value)), f"mi355rt_debug_set_knob({name})", L)
 

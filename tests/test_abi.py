@@ -73,8 +73,8 @@ def test_no_cpu_fallback_without_a_device(native, abi):
 
 
 def test_product_libraries_read_no_environment_and_hold_no_retired_kernels(native):
-    """include/mi355rt.h promises that nothing but the structs selects behaviour: neither library may import getenv.  The two
-    earlier generations of the mesh path (state machine, walk pool) are compiled into the tests' reference build only."""
+    """include/mi355rt.h promises that nothing but the structs selects behaviour: neither library may import getenv.  The
+    earliest generation of the mesh path (the state machine) is compiled into the tests' reference build only."""
     import subprocess
     b = pkg("build")
     for so in (b.DEVICE_SO, b.HOST_SO):

@@ -1,5 +1,5 @@
 """CPU-only checks of bench.py's bookkeeping: the counters file is only trusted for the kernel sources it was taken on, and the
-committed file matches the committed sources (so the driver's bench line says "pmc": "fresh")."""
+committed file matches the committed sources (so the driver's bench line says "pmc": "committed (hash-matched)")."""
 import importlib
 import json
 import os
@@ -22,7 +22,7 @@ def test_committed_pmc_counters_belong_to_the_committed_kernel_sources():
             assert bench.load_pmc(wl, build.kernel_hash())[1] == "absent"
             continue
         rec, state = bench.load_pmc(wl, build.kernel_hash())
-        assert state == "fresh" and rec["valu_wave_insts_per_step"] > 0 and rec["hbm_bytes_per_step"] > 0 and 0 < rec["valu_lane_utilisation"] <= 1
+        assert state == bench.PMC_OK == "committed (hash-matched)" and rec["valu_wave_insts_per_step"] > 0 and rec["hbm_bytes_per_step"] > 0 and 0 < rec["valu_lane_utilisation"] <= 1
         # every fraction bench.py can print from these counters is physical: issue rate below the peak for any plausible kernel time
         assert rec["kernel"].startswith("k_render_ctr")
 
@@ -38,7 +38,7 @@ def test_stale_or_missing_counters_are_reported_not_used(tmp_path, monkeypatch):
     assert bench.load_pmc("cornell-box-800x600x256-d30", "abc") == (None, "absent")
     good = {"kernel": "k_render_ctr_simple", "valu_wave_insts_per_step": 1.0, "hbm_bytes_per_step": 2.0, "valu_lane_utilisation": 0.5}
     p.write_text(json.dumps({"kernel_hash": "abc", "workloads": {"cornell-box-800x600x256-d30": good}}))
-    assert bench.load_pmc("cornell-box-800x600x256-d30", "abc", "k_render_ctr_simple") == (good, "fresh")
+    assert bench.load_pmc("cornell-box-800x600x256-d30", "abc", "k_render_ctr_simple") == (good, bench.PMC_OK)
     assert bench.load_pmc("cornell-box-800x600x256-d30", "abc", "k_render_ctr_nomesh") == (None, "other-kernel")   # counters of one variant, time of another
     part = {k: v for k, v in good.items() if k != "hbm_bytes_per_step"}                                              # a counter pass failed
     p.write_text(json.dumps({"kernel_hash": "abc", "workloads": {"cornell-box-800x600x256-d30": part}}))

@@ -68,6 +68,95 @@ def test_failed_launch_relays_the_code_or_falls_back_to_one_process(tmp_path):
     assert "no GPU visible" in out.stderr
 
 
+HANG_STUB = textwrap.dedent("""
+    import json, os, subprocess, sys, time
+    # a launcher that never gets anywhere -- with a child of its own, as torch.distributed.run has its ranks
+    kid = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
+    json.dump({"pid": os.getpid(), "kid": kid.pid}, open(os.environ["STUB_OUT"], "w"))
+    if os.environ.get("STUB_LINE") == "1":
+        print(json.dumps({"metric": "stub", "value": 2.0}), flush=True)      # the measurement is out ... and then teardown hangs
+    time.sleep(600)
+""")
+FALLBACK_STUB = textwrap.dedent("""
+    import json, os, sys
+    json.dump({"argv": sys.argv[1:], "launch": os.environ.get("MI355RT_BENCH_LAUNCH"), "info": json.loads(os.environ.get("MI355RT_BENCH_FALLBACK_INFO", "null"))},
+              open(os.environ["FALLBACK_OUT"], "w"))
+    print(json.dumps({"metric": "fallback-stub", "launch": os.environ.get("MI355RT_BENCH_LAUNCH"), **json.loads(os.environ.get("MI355RT_BENCH_FALLBACK_INFO", "{}"))}), flush=True)
+""")
+
+
+def gone(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return True
+    try:                                                      # a zombie that nobody reaped yet is gone for our purposes
+        return open(f"/proc/{pid}/stat").read().split(") ")[1][0] == "Z"
+    except OSError:
+        return True
+
+
+def run_with(tmp_path, stub_text, args, **env_extra):
+    stub = tmp_path / "hang_launcher.py"
+    stub.write_text(stub_text)
+    fb = tmp_path / "fallback_stub.py"
+    fb.write_text(FALLBACK_STUB)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MI355RT_BENCH_FORCE_DIST", "MI355RT_BENCH_REHEARSE")}
+    env.update(MI355RT_BENCH_LAUNCHER=f"{sys.executable} {stub}", MI355RT_BENCH_FALLBACK_CMD=f"{sys.executable} {fb}",
+               STUB_OUT=str(tmp_path / "stub.json"), FALLBACK_OUT=str(tmp_path / "fallback.json"), **env_extra)
+    import time
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, BENCH, *args], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    return out, time.monotonic() - t0
+
+
+def test_a_launch_that_hangs_is_killed_at_the_deadline_and_the_fallback_runs(tmp_path):
+    """a rendezvous or RCCL-init hang must not end as the DRIVER's kill with no line.  The launcher stub sleeps forever (so does
+    its own child); after --launch-timeout the parent ends the whole process group and starts the --single-process child, whose line says why."""
+    out, took = run_with(tmp_path, HANG_STUB, ["--gpus", "8", "--launch-timeout", "3"])
+    assert took < 30, took                                                       # 3 s deadline + 5 s SIGTERM wait at most + interpreter starts
+    ids = json.load(open(tmp_path / "stub.json"))
+    assert gone(ids["pid"]) and gone(ids["kid"])                                 # the launcher AND what it had started
+    assert "no result line within 3 s" in out.stderr and "starting ONE fresh process that drives all 8 devices" in out.stderr
+    fb = json.load(open(tmp_path / "fallback.json"))
+    assert fb["argv"][-1] == "--single-process" and fb["argv"][:2] == ["--gpus", "8"]
+    assert "timed out" in fb["launch"] and fb["launch"].startswith("fallback: one process drives 8 devices")
+    assert fb["info"] == {"fallback": True, "rank_launch_rc": 124, "rank_launch_timed_out": True, "rank_launch_seconds": fb["info"]["rank_launch_seconds"]}
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert out.returncode == 0 and line["fallback"] is True and line["rank_launch_timed_out"] is True and "timed out" in line["launch"]
+    # without the fallback the exit code says "timed out" the way timeout(1) does
+    out, _ = run_with(tmp_path, HANG_STUB, ["--gpus", "8", "--launch-timeout", "2"], MI355RT_BENCH_NO_FALLBACK="1")
+    assert out.returncode == 124 and "timed out" in out.stderr and out.stdout.strip() == ""
+
+
+def test_a_launch_that_hangs_in_teardown_keeps_its_line(tmp_path):
+    """The ranks printed their result line and then hang (destroy_process_group, the launcher's own exit): the line is relayed, the group is
+    ended after --teardown-grace, the exit code is 0 and NO second measurement is made."""
+    out, took = run_with(tmp_path, HANG_STUB, ["--gpus", "4", "--launch-timeout", "30", "--teardown-grace", "2"], STUB_LINE="1")
+    assert out.returncode == 0 and took < 30, (out.returncode, took, out.stderr)
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert [json.loads(l) for l in lines] == [{"metric": "stub", "value": 2.0}]          # one line: the launch's
+    assert not (tmp_path / "fallback.json").exists() and "teardown" in out.stderr
+    ids = json.load(open(tmp_path / "stub.json"))
+    assert gone(ids["pid"]) and gone(ids["kid"])
+
+
+def test_a_launch_that_printed_its_line_and_then_failed_is_not_repeated(tmp_path):
+    """ADVICE r4 (bench.py:426): ranks that die in teardown AFTER their line must not trigger the fallback -- a second line under the same n_gpus
+    would be a different kind of measurement.  The launcher's code is passed on."""
+    out, seen, _ = run_parent(tmp_path, ["--gpus", "2"], STUB_LINE="1", STUB_RC="7", MI355RT_BENCH_FALLBACK_CMD=f"{sys.executable} -c raise_SystemExit(99)")
+    assert out.returncode == 7 and "no fallback" in out.stderr
+    assert [json.loads(l) for l in out.stdout.strip().splitlines()] == [{"metric": "stub", "value": 1.0}]
+
+
+def test_the_rank_path_bounds_its_rendezvous_and_announces_itself():
+    src = open(BENCH).read()
+    assert 'init_process_group(backend="nccl", device_id=dev, timeout=limit)' in src and "--rendezvous-timeout" in src
+    assert src.index("on device {local_rank}") < src.index('init_process_group(backend="gloo"')      # the per-rank line comes BEFORE the first collective
+    bench = __import__("importlib").import_module("bench")
+    assert bench.frames_in_flight("veach-mis-1280x720x1024-d16") == 1 and bench.frames_in_flight("cornell-box-800x600x256-d30") == 2
+
+
 def test_a_launcher_that_cannot_be_started_is_a_failed_launch(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MI355RT_BENCH_FORCE_DIST", "MI355RT_BENCH_REHEARSE")}
     env.update(MI355RT_BENCH_LAUNCHER=str(tmp_path / "no_such_launcher"), MI355RT_BENCH_NO_FALLBACK="1")

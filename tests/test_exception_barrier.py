@@ -61,3 +61,15 @@ def test_every_entry_point_sits_behind_the_barrier():
     assert api.count("catch") >= 5
     png = open(os.path.join(ROOT, "raytracer-rust_amd/csrc/host/png_write.cpp")).read()
     assert png.count("return mi355rt_host::guard(") == 3
+    # ... and EVERY `int mi355rt_*(...)` the host library defines, whichever file it lives in (bvh_build* and scene_load_json had
+    # ad-hoc handlers that could throw again while building their message and had no catch (...))
+    host_dir = os.path.join(ROOT, "raytracer-rust_amd/csrc/host")
+    seen = []
+    for name in sorted(os.listdir(host_dir)):
+        if not name.endswith(".cpp"):
+            continue
+        src = open(os.path.join(host_dir, name)).read()
+        for m in re.finditer(r"\n(?:extern \"C\" )?int (mi355rt_\w+)\((?:[^()]|\([^()]*\))*\) \{\n((?:.*\n){1,6})", src):
+            seen.append(m.group(1))
+            assert "mi355rt_host::guard(" in m.group(2), f"{name}: {m.group(1)} does not open with the barrier"
+    assert {"mi355rt_bvh_build", "mi355rt_bvh_build_threads", "mi355rt_scene_load_json", "mi355rt_write_png", "mi355rt_write_pfm", "mi355rt_write_exr"} <= set(seen), seen

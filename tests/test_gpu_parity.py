@@ -118,13 +118,15 @@ def knobs(native):
 @pytest.mark.parametrize("name", ["teapot", "semesterbild"])
 def test_mesh_kernels_equal_the_lockstep_walk(name, native, oracle_mod, abi, knobs):
     """Every generation of the mesh path performs the same arithmetic per ray: the product's wavefront kernel (automatic choice), its
-    per-lane fallback loop k_render_ctr_mesh, and -- from the tests' reference build (-DMI355RT_REFS), where they were retired to --
-    the wave-scheduled state machine (any trav_min) and the LDS walk pool (4 and 9 walker waves) must be bit-identical to each other,
-    and identical to the oracle where the path is exact."""
+    per-lane fallback loop k_render_ctr_mesh, and -- from the tests' reference build (-DMI355RT_REFS), where it was retired to --
+    the wave-scheduled state machine (any trav_min, with and without its inline root test) must be bit-identical to each other,
+    and identical to the oracle where the path is exact.  (Round 2's LDS walk pool was a fourth reference until round 5: it reported
+    a stall once whose cause was never established, and a test that renders again after such a report forgives what nobody can explain;
+    the kernel was removed rather than retried -- DESIGN.md 4.1d.)"""
     host, device = native
     R = device.refs()
-    assert not device.lib().mi355rt_debug_has_variant(2) and not device.lib().mi355rt_debug_has_variant(5)     # retired from the product library
-    assert R.mi355rt_debug_has_variant(2) and R.mi355rt_debug_has_variant(5)
+    assert not device.lib().mi355rt_debug_has_variant(2)                     # retired from the product library
+    assert R.mi355rt_debug_has_variant(2) and not R.mi355rt_debug_has_variant(5) and not R.mi355rt_debug_has_variant(6)     # (5 / 6 were the walk pool: in no library)
     sc = load_for_both(name, oracle_mod, host, width=96, height=64, spp=6, max_depth=12)
     ctx = device.Context(0)
     ctx.set_scene(sc, sc.camera, sc.settings)
@@ -138,22 +140,9 @@ def test_mesh_kernels_equal_the_lockstep_walk(name, native, oracle_mod, abi, kno
     outs = []
     for library, kv in ((None, {"kernel": 1}), (None, {}), (None, {"kernel": 7}), (None, {"kernel": 10}),
                         (R, {"kernel": 1}), (R, {"kernel": 7}),
-                        (R, {"kernel": 2, "trav_min": 1}), (R, {"kernel": 2, "trav_min": 64}), (R, {"kernel": 2}),
-                        (R, {"kernel": 5}), (R, {"kernel": 5, "walkers": 9, "trav_min": 1}),                  # walk pool: 4 and 9 walker waves
-                        (R, {"kernel": 5, "inline_steps": 0, "pool_patience": 500, "trav_min": 48})):
+                        (R, {"kernel": 2, "trav_min": 1}), (R, {"kernel": 2, "trav_min": 64}), (R, {"kernel": 2}), (R, {"kernel": 2, "inline_steps": 0})):
         knobs(library, **kv)
-        try:
-            gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(), library=library)
-        except device.RenderError as e:
-            # A kernel of the reference build reported its watchdog once in round 3 (5 waves = the 4 walkers + 1 producer of a 4-walker
-            # walk pool; cause not found by inspection of the ring protocol) -- a clean MI355RT_ERR_HIP, never a wrong image.
-            # Since round 4 the pool's watchdogs count polls without PROGRESS and the message names kernel and wait.  It is a bit-identity
-            # reference, not a product kernel: one retry, the full message in the warning.  A product-library kernel gets no second chance.
-            if library is None or "watchdog" not in str(e):
-                raise
-            import warnings
-            warnings.warn(f"reference kernel {kv} reported its watchdog once: {e}")
-            gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(), library=library)
+        gp, gl, st = device.render(sc, sc.camera, sc.settings, abi.Options.make(), library=library)     # a kernel watchdog fails the test, once, with its message: no second render
         outs.append((gp, gl, st.rays))
     for i, (gp, gl, rays) in enumerate(outs[1:], 1):
         assert np.array_equal(gl.view(np.uint32), outs[0][1].view(np.uint32)) and np.array_equal(gp, outs[0][0]) and rays == outs[0][2], f"configuration {i}"

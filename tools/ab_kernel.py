@@ -1,5 +1,5 @@
 """A/B of the counter-mode kernel variants / trav_min in one process, on the reference build (-DMI355RT_REFS: the product sources plus
-the retired state-machine and walk-pool kernels); variants are chosen with the diagnostic knobs of mi355rt_debug_set_knob."""
+the retired state-machine kernel); variants are chosen with the diagnostic knobs of mi355rt_debug_set_knob."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import pkg
@@ -11,7 +11,7 @@ WL = {"cornell": ("data/scenes/tungsten/cornell-box/scene.json", 800, 600, 256, 
       "teapot": ("data/scenes/tungsten/teapot/scene.json", 800, 600, 64, 30, True)}
 SETTINGS = [("lockstep", {"kernel": "1"}), ("wavefront", {"kernel": "7"})] + [(f"sm{t}", {"kernel": "2", "trav_min": str(t)}) for t in (16, 24, 32)] \
          + [("sm24i1", {"kernel": "2", "trav_min": "24", "inline_steps": "1"})]
-ENV_KEYS = ("kernel", "trav_min", "inline_steps", "walkers", "pool_patience")
+ENV_KEYS = ("kernel", "trav_min", "inline_steps")
 REFS = device.refs()
 if os.environ.get("AB_KERNEL_SETTINGS"):     # "name=KERNEL:TRAV_MIN[:INLINE_STEPS[:WALKERS[:PATIENCE]]],..."
     SETTINGS = [(kv.split("=")[0], dict(zip(ENV_KEYS, kv.split("=")[1].split(":")))) for kv in os.environ["AB_KERNEL_SETTINGS"].split(",")]

@@ -9,9 +9,7 @@ for name in ("teapot", "semesterbild"):
     sc = load_for_both(name, oracle, host, width=96, height=64, spp=6, max_depth=12)
     for rep in range(3):
         for library, kv in ((None, {"kernel": 1}), (None, {}), (R, {"kernel": 1}), (R, {"kernel": 7}),
-                            (R, {"kernel": 2, "trav_min": 1}), (R, {"kernel": 2}),
-                            (R, {"kernel": 5}), (R, {"kernel": 5, "walkers": 9, "trav_min": 1}),
-                            (R, {"kernel": 5, "inline_steps": 0, "pool_patience": 500, "trav_min": 48})):
+                            (R, {"kernel": 2, "trav_min": 1}), (R, {"kernel": 2}), (R, {"kernel": 2, "inline_steps": 0})):
             L = library or device.lib()
             device.clear_knobs(L)
             for k, v in kv.items(): device.set_knob(k, v, L)
