@@ -382,7 +382,7 @@ def make_result(args, abi, build, rtdist, scene, plan, world, elapsed, render_ms
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": f"synthetic (the reference's own scene file {path}; no external data)",
         "config": {"workload": args.workload, "scene": path, "width": W, "height": H, "spp": spp, "max_bounces": depth,
-                   "rng": "ctr (Philox4x32-10 per ray)", "parallelism": f"row strips of {plan.strip_rows} dealt round-robin over {world} GPU(s)"
+                   "rng": "ctr (pcg4d counter hash: per-path base = pcg4d(x, sample, row key); block j after ray r = pcg4d(base + (0, 0, r, j)))", "parallelism": f"row strips of {plan.strip_rows} dealt round-robin over {world} GPU(s)"
                    + (f", {gather}" if gather else ""),
                    "frames_in_flight": depth_pipe},
         "launch": launch,

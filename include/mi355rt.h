@@ -163,7 +163,7 @@ typedef struct mi355rt_scene {
 
 /* ---- options that have no counterpart in the reference ---------------------------------------- */
 enum {
-    MI355RT_RNG_CTR = 0, /* counter-based per-ray Philox4x32-10 keyed by (row y; x, sample, ray, block).
+    MI355RT_RNG_CTR = 0, /* counter-based per-ray generator (pcg4d since round 5, Philox4x32-10 before) addressed by (row y; x, sample, ray, block).
                             GPU-native default; any tiling gives bit-identical images.           */
     MI355RT_RNG_REF = 1  /* replay of the reference stream: StdRng::seed_from_u64(y) shared by a
                             whole row (src/renderer.rs:91). One lane per row -- validation only.   */

@@ -62,6 +62,12 @@ def lib():
         L.oracle_u32_to_range11.restype = C.c_float
         L.oracle_u32_to_range11.argtypes = [C.c_uint32]
         L.oracle_philox4x32_10.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
+        L.oracle_philox4x32.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
+        L.oracle_pcg4d.argtypes = [C.c_uint32] * 4 + [C.c_void_p]
+        L.oracle_ctr_block.argtypes = [C.c_int] + [C.c_uint32] * 6 + [C.c_void_p]
+        L.oracle_set_ctr_gen.restype = C.c_int
+        L.oracle_set_ctr_gen.argtypes = [C.c_int]
+        L.oracle_get_ctr_gen.restype = C.c_int
         L.oracle_color_to_u32.restype = C.c_uint32
         L.oracle_color_to_u32.argtypes = [C.c_float] * 3
         L.oracle_scene_hit.restype = C.c_int
@@ -95,6 +101,34 @@ def philox(k0, k1, c0, c1, c2, c3):
     out = np.zeros(4, np.uint32)
     lib().oracle_philox4x32_10(k0, k1, c0, c1, c2, c3, out.ctypes.data)
     return out
+
+
+def philox_rounds(k0, k1, c0, c1, c2, c3, rounds):
+    out = np.zeros(4, np.uint32)
+    lib().oracle_philox4x32(k0, k1, c0, c1, c2, c3, rounds, out.ctypes.data)
+    return out
+
+
+def pcg4d(x, y, z, w):
+    out = np.zeros(4, np.uint32)
+    lib().oracle_pcg4d(x, y, z, w, out.ctypes.data)
+    return out
+
+
+def ctr_block(k0, k1, x, s, ray, j, gen=-1):
+    """The 4 words of block j of the event after ray `ray` of path (k0, k1; x, s); gen -1 = the generator in force."""
+    out = np.zeros(4, np.uint32)
+    lib().oracle_ctr_block(gen, k0, k1, x, s, ray, j, out.ctypes.data)
+    return out
+
+
+def set_ctr_gen(gen):
+    """Select the counter-mode generator (0 Philox4x32-10, 1 Philox4x32-7, 2 pcg4d) the oracle checks against; returns the previous one."""
+    return lib().oracle_set_ctr_gen(gen)
+
+
+def ctr_gen():
+    return lib().oracle_get_ctr_gen()
 
 
 def render(scene, camera, settings, options=None, threads=0, fold=-1, want_linear=True):

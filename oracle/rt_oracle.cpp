@@ -203,12 +203,18 @@ struct SamplerRef {                     // sequential row stream, call sites ren
 };
 
 // ------------------------------------------------------------------------------------------------
-// RNG, counter mode: Philox4x32-10 (Salmon et al., SC'11), one block = 4 words
+// RNG, counter mode.  The device library is built with ONE generator (rt_rng.h, MI355RT_CTR_GEN); the oracle holds all of them and is
+// told which one to check against (oracle_set_ctr_gen; default = what the product library ships):
+//   0  Philox4x32-10 (Salmon et al., SC'11), key = row key, counter = (x, sample, ray, block)
+//   1  Philox4x32-7, same addressing
+//   2  pcg4d (Jarzynski & Olano, JCGT 9(3), 2020): per-path base = pcg4d(x, sample, key lo, key hi); block j of the event after
+//      ray r = pcg4d(base.x, base.y, base.z + r, base.w + j)
+// One block = 4 words in every case; which word serves which draw is the same for all (SamplerCtr below).
 // ------------------------------------------------------------------------------------------------
-inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                          uint32_t out[4]) {
+inline void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int rounds,
+                       uint32_t out[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
         uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
@@ -218,6 +224,24 @@ inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, ui
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    philox4x32(k0, k1, c0, c1, c2, c3, 10, out);
+}
+inline void pcg4d(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t out[4]) {
+    x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u; z = z * 1664525u + 1013904223u; w = w * 1664525u + 1013904223u;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    out[0] = x; out[1] = y; out[2] = z; out[3] = w;
+}
+#ifndef ORACLE_CTR_GEN_DEFAULT
+#define ORACLE_CTR_GEN_DEFAULT 2                              // what the product library ships (rt_rng.h MI355RT_CTR_GEN)
+#endif
+static int g_ctr_gen = ORACLE_CTR_GEN_DEFAULT;
+inline void ctr_block(int gen, uint32_t k0, uint32_t k1, uint32_t x, uint32_t s, uint32_t ray, uint32_t j, uint32_t out[4]) {
+    if (gen == 2) { uint32_t b[4]; pcg4d(x, s, k0, k1, b); pcg4d(b[0], b[1], b[2] + ray, b[3] + j, out); }
+    else philox4x32(k0, k1, x, s, ray, j, gen == 1 ? 7 : 10, out);
+}
 
 struct SamplerCtr {
     static constexpr bool exact_libm = false;                  // counter mode: the platform's float functions (the device uses its native ones)
@@ -226,7 +250,7 @@ struct SamplerCtr {
     uint32_t cached_block = 0xFFFFFFFFu, cached_ray = 0xFFFFFFFFu, w[4];
     void load(uint32_t blockno) {
         if (cached_block != blockno || cached_ray != ray) {
-            philox4x32_10(k0, k1, x, s, ray, blockno, w);
+            ctr_block(g_ctr_gen, k0, k1, x, s, ray, blockno, w);
             cached_block = blockno; cached_ray = ray;
         }
     }
@@ -1151,6 +1175,14 @@ float oracle_u32_to_range11(uint32_t w) { return u32_to_range11(w); }
 void oracle_philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
     philox4x32_10(k0, k1, c0, c1, c2, c3, out);
 }
+void oracle_philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int rounds, uint32_t out[4]) { philox4x32(k0, k1, c0, c1, c2, c3, rounds, out); }
+void oracle_pcg4d(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t out[4]) { pcg4d(x, y, z, w, out); }
+// The 4 words of block j of the event after ray `ray` of path (k0, k1; x, s) under generator `gen` (-1: the one in force)
+void oracle_ctr_block(int gen, uint32_t k0, uint32_t k1, uint32_t x, uint32_t s, uint32_t ray, uint32_t j, uint32_t out[4]) { ctr_block(gen < 0 ? g_ctr_gen : gen, k0, k1, x, s, ray, j, out); }
+// Which counter-mode generator oracle_render / oracle_scatter_ctr use from now on (0 / 1 / 2, see above); returns the previous one.  Not
+// thread-safe against a render in progress: set it between renders.
+int oracle_set_ctr_gen(int gen) { const int old = g_ctr_gen; if (gen >= 0 && gen <= 2) g_ctr_gen = gen; return old; }
+int oracle_get_ctr_gen(void) { return g_ctr_gen; }
 uint32_t oracle_color_to_u32(float r, float g, float b) { return color_to_u32(csqrt(Col{r, g, b})); }
 
 // Closest hit of one ray against the scene (HittableList::hit with t_min = EPSILON, t_max = inf).

@@ -197,7 +197,10 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane, cons
 // FASTN: see normalized() (rt_math.h).  TRY1: try 1 of the unit-ball draw comes from a second Philox block drawn in the lane itself, right after the
 // event's block, so the cooperative rounds start at try 2 and a second round is needed in 44 % of the iterations instead of all: cornell -0.9 %
 // on the Lambert-only kernel; every other kernel pays for the three more live registers with spills (+1.5 ... +23 %: profiles/r03_ab_inlane_try1.txt).
-template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, bool FASTN = false, int TRY1 = 0, class WC>
+// REKEY (wavefront kernel: a path's generator state is not carried in its slot): the state is derived from the sample index HERE, once, for continuing
+// and freshly dealt lanes together, right in front of the event's block -- instead of by the caller when the slot is loaded (live through the hit record,
+// the material read and the radiance store) and a second time where fresh samples are dealt.
+template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, bool FASTN = false, int TRY1 = 0, bool REKEY = false, class WC>
 DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
                              PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
@@ -222,7 +225,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
     }
     prof.mark(2);
     bool fresh = false;
-    if (wc.deal(P, can_take && !live, lane, ps.sidx)) { start_path(P, ps.sidx, ps.rng, ps.px, ps.py); fresh = true; live = true; ++n_paths; }
+    if (wc.deal(P, can_take && !live, lane, ps.sidx)) { if constexpr (!REKEY) start_path(P, ps.sidx, ps.rng, ps.px, ps.py); fresh = true; live = true; ++n_paths; }
     if constexpr (DROP_PRIO) __builtin_amdgcn_s_setprio(0);                               // the lockstep kernels' arithmetic half (see render_ctr_lockstep)
     if (__ballot(live) == 0ull) return !wc.exhausted();
     uint32_t ball_use = BALL_NONE; bool scattered = false;
@@ -265,7 +268,8 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
         // The branches therefore only PRODUCE the next state (fresh values, nothing carried through them) and the state is
         // overwritten for all lanes at the end: no conditional updates of loop-carried registers, no copies to merge them.
         f3 n_ro, n_thr; uint32_t n_ri;
-        if (!fresh) ps.rng.next_event();
+        if constexpr (REKEY) { if (live) { start_path(P, ps.sidx, ps.rng, ps.px, ps.py); ps.rng.set_ray(fresh ? 0u : ps.ray_index + 1u); } }
+        else if (!fresh) ps.rng.next_event();
         ps.rng.template load_block0<WIDE>();
         uint32_t blk1[4] = {0u, 0u, 0u, 0u};
         if constexpr (TRY1 >= 1) RngCtr::block<WIDE>(ps.rng.w, 1u, blk1);

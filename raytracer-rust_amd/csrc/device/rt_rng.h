@@ -60,8 +60,11 @@ DI void pcg4d(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t (&out)[4]
 //   0  Philox4x32-10, key = row key (64 bit), counter = (x, sample, ray, block)                      -- rounds 1-4
 //   1  Philox4x32-7, same addressing (Random123's Crush-resistant minimum)
 //   2  pcg4d: a per-path base = pcg4d(x, sample, key lo, key hi); block j of the event after ray r = pcg4d(base + (0, 0, r, j))
+// Shipped since round 5: 2.  Measured on the headline config (cornell 800x600x256, kernel ms, one process, interleaved: profiles/r05/ab_counter_generator.txt):
+// Philox4x32-10 14.57, Philox4x32-7 13.71 (-5.9 %), pcg4d 13.38 (-8.1 %); quality gates: tools/rng_battery.py (the addressed stream through a
+// SmallCrush-style battery: profiles/r05/rng_battery_*.txt) and tools/rng_image_gate.py (image means / RMSE against the reference-stream oracle).
 #ifndef MI355RT_CTR_GEN
-#define MI355RT_CTR_GEN 0
+#define MI355RT_CTR_GEN 2
 #endif
 constexpr int CTR_GEN = MI355RT_CTR_GEN;
 

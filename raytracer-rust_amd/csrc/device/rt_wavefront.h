@@ -38,6 +38,9 @@
 #ifndef MI355RT_AB_WF_WIDE
 #define MI355RT_AB_WF_WIDE true
 #endif
+#ifndef MI355RT_AB_WF_REKEY
+#define MI355RT_AB_WF_REKEY true                             // shade_and_regenerate derives the generator state itself (see there)
+#endif
 
 namespace mi355rt {
 
@@ -475,8 +478,10 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             Cand c; cand_reset(c);
             if (have) {
                 Slot::load_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index, c);
-                start_path(P, ps.sidx, ps.rng, ps.px, ps.py);                   // the RNG key is a function of the sample index
-                ps.rng.set_ray(ps.ray_index);
+                if constexpr (!(MI355RT_AB_WF_REKEY)) {
+                    start_path(P, ps.sidx, ps.rng, ps.px, ps.py);               // the RNG key is a function of the sample index
+                    ps.rng.set_ray(ps.ray_index);
+                }
             }
             bool live = have;
             const bool any_hit = have && c.idx != CAND_NONE;
@@ -484,7 +489,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             if (any_hit) finish_hit<HAS_MESH, HAS_MESH ? MI355RT_AB_WF_SHARED_TAIL : true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
             // (the priority stays raised through the material read, the radiance store and the work cursor's atomic: shade_and_regenerate
             // drops it to 0 where the arithmetic starts, DROP_PRIO; the list walk below reads primitives again and runs at PRIO_TOP)
-            shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true, false, MI355RT_AB_FASTN_WF>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
+            shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true, false, MI355RT_AB_FASTN_WF, 0, MI355RT_AB_WF_REKEY>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
             if (live) Slot::store_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index);    // a ray to trace: continuing or freshly generated
             const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
             if (lane == 0 && born != died) atomicAdd(&Q.ctrl[16], (uint32_t)(born - died));

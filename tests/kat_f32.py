@@ -70,6 +70,23 @@ def philox(k0, k1, c0, c1, c2, c3):
     return [c0, c1, c2, c3]
 
 
+def pcg4d(x, y, z, w):
+    """Jarzynski & Olano, "Hash Functions for GPU Rendering" (JCGT 9(3), 2020), listing of pcg4d, on Python integers."""
+    M32 = 0xFFFFFFFF
+    x, y, z, w = [(v * 1664525 + 1013904223) & M32 for v in (x, y, z, w)]
+    x = (x + y * w) & M32; y = (y + z * x) & M32; z = (z + x * y) & M32; w = (w + y * z) & M32
+    x, y, z, w = [v ^ (v >> 16) for v in (x, y, z, w)]
+    x = (x + y * w) & M32; y = (y + z * x) & M32; z = (z + x * y) & M32; w = (w + y * z) & M32
+    return [x, y, z, w]
+
+
+def ctr_block(k0, k1, x, s, ray, j):
+    """Counter-mode generator of the product since round 5 (rt_rng.h, CTR_GEN 2): a per-path base pcg4d(x, sample, key lo, key hi); block j of
+    the event after ray `ray` = pcg4d(base.x, base.y, base.z + ray, base.w + j)."""
+    b = pcg4d(x, s, k0, k1)
+    return pcg4d(b[0], b[1], (b[2] + ray) & 0xFFFFFFFF, (b[3] + j) & 0xFFFFFFFF)
+
+
 class CtrDraws:
     """Draw addressing of the counter mode (DESIGN.md 4.1): the scatter event of `ray` reads random::<f32>() number k from
     block 0 word k, and rejection try j of random_in_unit_sphere from block j words 1..3."""
@@ -79,7 +96,7 @@ class CtrDraws:
 
     def block(self, j):
         k0, k1, x, s, ray = self.key
-        return philox(k0, k1, x, s, ray, j)
+        return ctr_block(k0, k1, x, s, ray, j)
 
     def uniform(self, k):
         return u01(self.block(0)[k])

@@ -162,6 +162,8 @@ def check_hit(name, want, hit, out9):
 def test_philox_and_float_conversions_of_the_independent_restatement(oracle_mod):
     for args in [(0, 0, 0, 0, 0, 0), (0xa4093822, 0x299f31d0, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (1, 2, 3, 4, 5, 6)]:
         assert K.philox(*args) == [int(v) for v in oracle_mod.philox(*args)]
+        assert K.pcg4d(*args[:4]) == [int(v) for v in oracle_mod.pcg4d(*args[:4])]
+        assert K.ctr_block(*args) == [int(v) for v in oracle_mod.ctr_block(*args, gen=2)] == [int(v) for v in oracle_mod.ctr_block(*args)]   # (2 = the generator in force)
     for w in [0, 1, 0xFF, 0x100, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0x12345678]:
         assert _bits([K.u01(w)])[0] == _bits([oracle_mod.lib().oracle_u32_to_f01(w)])[0]
         assert _bits([K.range11(w)])[0] == _bits([oracle_mod.lib().oracle_u32_to_range11(w)])[0]

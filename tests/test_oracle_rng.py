@@ -4,8 +4,17 @@ ChaCha12 / seed_from_u64 vectors: SURVEY.md Appendix A -- captured from the surv
 reproduced the reference's committed docs/semesterbild.png pixel-for-pixel along row prefixes
 (rand 0.9.1 StdRng; the crate source is not in the container).
 Philox4x32-10 vectors: the Random123 distribution's kat_vectors (Salmon et al., SC'11).
+pcg4d (the counter-mode generator since round 5; Jarzynski & Olano, JCGT 9(3) 2020): the paper publishes the function, no vectors -- it is
+pinned by three restatements written independently from the listing (C++ in the oracle, vectorised numpy in tools/rng_battery.py, Python
+integers in tests/kat_f32.py), by its algebra (every step is invertible: the inverse below undoes it, so it is a bijection of 128 bits and the
+blocks of one path are distinct) and by the vectors frozen here from their agreement.
 """
+import os
+import sys
+
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 APPENDIX_A = {  # seed: (key words, u32[0..3], u32[16..17], u32[62..65], u32[128])
     0: ("f973f2ec 45cdb581 7346f087 ad6cad06 e3a3d0d0 67e71733 72ea9bf2 fe7d8ad7", "cd2c6f7f bb2a3fb2 8e27697b c6017c94",
@@ -64,8 +73,52 @@ def test_philox4x32_10_kat(oracle_mod):
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
+PCG4D_VECTORS = {      # frozen from the agreement of the three restatements (see the module docstring)
+    (0, 0, 0, 0): [251852841, 760645481, 850445371, 3542436074],
+    (1, 2, 3, 4): [908250390, 4044648920, 3775961919, 45698095],
+}
+
+
+def pcg4d_inverse(x, y, z, w):
+    """Undoes pcg4d step by step on Python integers: the multiply-adds in reverse order, the xorshift by 16 (its own inverse), the LCG step by
+    the modular inverse of its multiplier."""
+    M = 1 << 32
+    w = (w - y * z) % M; z = (z - x * y) % M; y = (y - z * x) % M; x = (x - y * w) % M
+    x, y, z, w = [v ^ (v >> 16) for v in (x, y, z, w)]
+    w = (w - y * z) % M; z = (z - x * y) % M; y = (y - z * x) % M; x = (x - y * w) % M
+    inv = pow(1664525, -1, M)
+    return [((v - 1013904223) * inv) % M for v in (x, y, z, w)]
+
+
+def test_pcg4d_three_restatements_vectors_and_bijection(oracle_mod):
+    sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import kat_f32 as K
+    import rng_battery as B
+    for args, want in PCG4D_VECTORS.items():
+        assert oracle_mod.pcg4d(*args).tolist() == want == K.pcg4d(*args)
+    rng = np.random.default_rng(20251005)
+    v = rng.integers(0, 1 << 32, size=(4, 4096), dtype=np.uint64).astype(np.uint32)
+    v[:, :8] = np.array([[0, 1, 0xFFFFFFFF, 0x80000000, 0, 0xFFFFFFFF, 7, 0x7FFFFFFF]] * 4, np.uint32)          # edge words
+    nb = B.pcg4d(v[0], v[1], v[2], v[3])
+    for i in range(0, 4096, 37):
+        a = [int(v[k, i]) for k in range(4)]
+        out = oracle_mod.pcg4d(*a).tolist()
+        assert out == K.pcg4d(*a) == [int(nb[k][i]) for k in range(4)]
+        assert pcg4d_inverse(*out) == a                                    # a bijection of 128 bits
+    # the addressing of the product: base = pcg4d(x, sample, key lo, key hi); block j after ray r = pcg4d(base + (0, 0, r, j))
+    for (k0, k1, x, s, r, j) in [(5, 0, 1, 2, 0, 0), (5, 0, 1, 2, 3, 1), (0xFFFFFFFF, 0xFFFFFFFF, 799, 255, 29, 7)]:
+        b = K.pcg4d(x, s, k0, k1)
+        want = K.pcg4d(b[0], b[1], (b[2] + r) & 0xFFFFFFFF, (b[3] + j) & 0xFFFFFFFF)
+        assert oracle_mod.ctr_block(k0, k1, x, s, r, j, gen=2).tolist() == want == K.ctr_block(k0, k1, x, s, r, j)
+        assert [int(w[0]) for w in B.block("pcg4d", *[np.array([t], np.uint32) for t in (k0, k1, x, s, r, j)])] == want
+    assert oracle_mod.ctr_gen() == 2                                       # what oracle.render's counter mode uses unless a test selects another
+    # generators 0 / 1 keep Philox's addressing (A/B builds of the device library: -DMI355RT_CTR_GEN=0 / 1)
+    assert oracle_mod.ctr_block(1, 2, 3, 4, 5, 6, gen=0).tolist() == oracle_mod.philox(1, 2, 3, 4, 5, 6).tolist()
+    assert oracle_mod.ctr_block(1, 2, 3, 4, 5, 6, gen=1).tolist() == oracle_mod.philox_rounds(1, 2, 3, 4, 5, 6, 7).tolist() != oracle_mod.philox(1, 2, 3, 4, 5, 6).tolist()
+
+
 def test_ctr_stream_first_sample_of_a_row_is_keyed_by_row(oracle_mod, abi):
     """Two rows never share a key and a seed offset of k equals shifting the row by k."""
-    a = oracle_mod.philox(5, 0, 1, 2, 0, 0).tolist()
-    b = oracle_mod.philox(6, 0, 1, 2, 0, 0).tolist()
+    a = oracle_mod.ctr_block(5, 0, 1, 2, 0, 0).tolist()
+    b = oracle_mod.ctr_block(6, 0, 1, 2, 0, 0).tolist()
     assert a != b
