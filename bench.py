@@ -132,9 +132,15 @@ def main(argv=None):
     ap.add_argument("--pipeline", type=int, default=0,
                     help="frames in flight (own stream + workspace each): 2 lets frame k's resolve + gather overlap frame k+1's tracing. "
                          "0 = auto: 1 on one GPU (clean per-kernel timing), 2 on several")
+    ap.add_argument("--share", type=int, default=0,
+                    help="mi355rt_context_set_share of every frame slot: each frame's persistent kernel launches 1/share of the resident grid (0 = auto: the workload's "
+                         "measured choice with several GPUs, 1 on one GPU)")
     ap.add_argument("--tail-parts", type=int, default=0,
                     help="after the timed region also time 1/P-image launches (strip part p of P, every p) on this GPU: "
                          "what one of P GPUs would run; reports ideal (full/P) vs measured")
+    ap.add_argument("--inflight", default="",
+                    help="after the timed region also time frames in flight: a comma list of FxD (F contexts + streams, each launching 1/D of the resident "
+                         "grid: mi355rt_context_set_share), at full size and -- with --tail-parts P -- at 1/P image; e.g. 1x1,2x1,2x2,3x3,4x4")
     ap.add_argument("--save-png", default="")
     ap.add_argument("--launch-timeout", type=float, default=200.0,
                     help="`--gpus N` as typed: seconds the self-started N-rank launch has to print its result line before its process group is "
@@ -205,15 +211,20 @@ def main(argv=None):
     plan = rtdist.make_plan(H, W, world)
     opt = plan.options_for(abi, rank)
     n_local_rows = len(plan.rows[rank])
-    depth_pipe = args.pipeline if args.pipeline > 0 else (frames_in_flight(args.workload) if use_dist else 1)
+    depth_pipe, share = (args.pipeline, args.share if args.share > 0 else 1) if args.pipeline > 0 else (frames_in_flight(args.workload) if use_dist else (1, 1))
+    if args.share > 0:
+        share = args.share
+    args.share_used = share
     # One frame slot = its own context (radiance workspace, work counters), output buffer and stream, so that two frames
     # never share scratch memory.  The scene is resident in HBM in every slot from here on.
     slots = []
+    streams, stream_info = ([torch.cuda.current_stream()], None) if depth_pipe == 1 else concurrent_streams(torch, dev, depth_pipe)
+    args.stream_info = stream_info
     for i in range(depth_pipe):
         ctx = device.Context(local_rank)
+        ctx.set_share(share)
         ctx.set_scene(scene, scene.camera, scene.settings)
-        slots.append({"ctx": ctx, "local": torch.zeros((plan.max_rows, W), dtype=torch.int32, device=dev),
-                      "stream": torch.cuda.current_stream() if depth_pipe == 1 else torch.cuda.Stream(device=dev)})
+        slots.append({"ctx": ctx, "local": torch.zeros((plan.max_rows, W), dtype=torch.int32, device=dev), "stream": streams[i]})
     ctx0 = slots[0]["ctx"]
 
     def sync_all():
@@ -286,8 +297,11 @@ def main(argv=None):
         one_shot = measure_one_shot(abi, device, scene)
     tail = None
     if args.tail_parts > 1 and world == 1:
-        tail = measure_tail(abi, rtdist, slots, H, W, args.tail_parts, max(3, args.steps // 2), render_ms_per_step, torch, device, scene, resolve_ms_per_step)
+        tail = measure_tail(abi, rtdist, slots, H, W, args.tail_parts, max(3, args.steps // 2), render_ms_per_step, torch, device, scene, resolve_ms_per_step, args.workload)
 
+    inflight = None
+    if args.inflight and world == 1:
+        inflight = measure_inflight(abi, rtdist, torch, device, scene, local_rank, H, W, args.inflight, args.tail_parts, max(4, args.steps // 2))
     result = None
     if rank == 0:
         launch = os.environ.get("MI355RT_BENCH_LAUNCH") or ("external launcher (RANK / WORLD_SIZE were in the environment)" if "RANK" in os.environ else "direct: one process, one GPU")
@@ -299,7 +313,7 @@ def main(argv=None):
                              launches / max(args.steps, 1), local_samples, st, variant, depth_pipe,
                              gather=(f"RCCL {rtdist.collective_name(rehearse)} of the packed rows" if use_dist else ""),
                              launch=launch, dist_info=dist_info, tail=tail, image_checksum=image_checksum,
-                             extras={**({"one_shot": one_shot} if one_shot else {}),
+                             extras={**({"one_shot": one_shot} if one_shot else {}), **({"inflight": inflight} if inflight else {}),
                                      **({"rehearsal": "all ranks on cuda:0 over gloo -- plumbing check only, NOT a measurement"} if rehearse else {}),
                                      **({"forced_dist": "one rank through the RCCL branch (process group, barrier, all_gather_into_tensor, all_reduce) -- a check of the calls, not a multi-GPU measurement"} if use_dist and world == 1 else {})})
         if args.save_png and final_image is not None:
@@ -321,11 +335,68 @@ def main(argv=None):
 # leave, which hides part of the launch tail of a 1/N-image frame -- where the workspace is small.  Measured at 1/8 image
 # (profiles/r04/tail_eighth_image_two_streams.txt): cornell 0.856 -> 0.888, teapot 0.539 -> 0.742, semesterbild 0.559 -> 0.672 of ideal, but
 # veach-mis 0.941 -> 0.795 (two 1.4 GB workspaces alternating cost more than the overlap buys).
-FRAMES_IN_FLIGHT = {"veach-mis-1280x720x1024-d16": 1}
+# Round 5: every frame slot's context is told its SHARE of the device (mi355rt_context_set_share): with F frames in flight each persistent kernel launches
+# 1 / share of the resident grid, so the launches are co-resident and a draining frame shares the SIMDs with frames in their steady state.  Measured at
+# 1/8 image, steady-state time per frame against (full-frame kernels / 8) (profiles/r05/inflight_*.txt): cornell 0.857 (1 frame) -> 0.953 (4 frames, share 4),
+# teapot 0.518 -> 0.836 (4, share 2), semesterbild 0.572 -> 0.876 (4, 4), veach-mis 0.940 -> 0.949 (4, 4).  More than 4 streams buy nothing: HIP multiplexes
+# streams onto 4 hardware queues (6 x 1/6: 0.69, 8 x 1/8: 0.52).
+FRAMES_IN_FLIGHT = {"teapot-800x600x256-d64": (4, 2)}     # workload -> (frames in flight, share of the device per frame); default (4, 4)
 
 
 def frames_in_flight(workload):
-    return FRAMES_IN_FLIGHT.get(workload, 2)
+    return FRAMES_IN_FLIGHT.get(workload, (4, 4))
+
+
+_STREAM_CLASSES = {}
+
+
+def concurrent_streams(torch, dev, want, pool=24):
+    """`want` torch streams of device `dev` that really run CONCURRENTLY with each other, plus a record of how they were found.
+    Frames in flight only overlap when their streams sit on different hardware queues, and HIP multiplexes streams onto GPU_MAX_HW_QUEUES (4)
+    queues in an order the caller cannot see: of 12 streams created in a row, (0, 1, 2, 3) shared a queue between two of them while (4, 5, 6, 7) did
+    not (tools/stream_queue_probe.py, profiles/r05/stream_queue_probe.txt) -- and four frames on three queues lose a third of the device.  So the
+    streams are PROBED: a one-block spin kernel (torch.cuda._sleep) on two streams takes T when they overlap and 2T when they share a queue; every
+    new stream is compared with one representative of each queue class found so far.  A few milliseconds, once per process and device."""
+    key = (dev.index if hasattr(dev, "index") else int(dev))
+    if key not in _STREAM_CLASSES:
+        info = {"method": "torch.cuda._sleep pair probe", "pool": pool}
+        streams = [torch.cuda.Stream(device=dev) for _ in range(pool)]
+        classes = []
+        try:
+            def pair_ms(a, b, cycles):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                with torch.cuda.stream(a):
+                    torch.cuda._sleep(cycles)
+                with torch.cuda.stream(b):
+                    torch.cuda._sleep(cycles)
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t0) * 1e3
+            cycles = 1_000_000
+            pair_ms(streams[0], streams[0], cycles)                                  # warm
+            serial = min(pair_ms(streams[0], streams[0], cycles) for _ in range(3))  # two spins on ONE stream: 2T
+            if serial < 0.8:                                                         # aim at T ~ 1 ms: well above launch overheads
+                cycles = int(cycles * 2.0 / max(serial, 1e-3)); serial = min(pair_ms(streams[0], streams[0], cycles) for _ in range(3))
+            info.update(spin_pair_serial_ms=round(serial, 3))
+            for s in streams:
+                shared = False
+                for rep in classes:
+                    if min(pair_ms(rep, s, cycles), pair_ms(rep, s, cycles)) > 0.75 * serial:   # (overlap: ~0.5 x serial)
+                        shared = True
+                        break
+                if not shared:
+                    classes.append(s)
+                if len(classes) >= 8:
+                    break
+            info.update(queue_classes_found=len(classes))
+        except Exception as e:                                                        # no _sleep on this build, ...: the first streams, unprobed -- and the line says so
+            info.update(method=f"unprobed ({e})", queue_classes_found=None)
+            classes = []
+        rest = [s for s in streams if all(s is not c for c in classes)]
+        _STREAM_CLASSES[key] = (classes, rest, info)
+    classes, rest, info = _STREAM_CLASSES[key]
+    picked = (classes + rest)[:want]
+    return picked, dict(info, wanted=want, distinct=min(want, len(classes)))
 
 
 def product_modules():
@@ -384,7 +455,8 @@ def make_result(args, abi, build, rtdist, scene, plan, world, elapsed, render_ms
         "config": {"workload": args.workload, "scene": path, "width": W, "height": H, "spp": spp, "max_bounces": depth,
                    "rng": "ctr (pcg4d counter hash: per-path base = pcg4d(x, sample, row key); block j after ray r = pcg4d(base + (0, 0, r, j)))", "parallelism": f"row strips of {plan.strip_rows} dealt round-robin over {world} GPU(s)"
                    + (f", {gather}" if gather else ""),
-                   "frames_in_flight": depth_pipe},
+                   "frames_in_flight": depth_pipe, "share_of_device_per_frame": getattr(args, "share_used", 1),
+                   **({"streams": args.stream_info} if getattr(args, "stream_info", None) else {})},
         "launch": launch,
         **({"distributed": dist_info} if dist_info else {}),
         "roofline": {"bound": "valu", "kernel": KERNEL_NAMES.get(variant, "k_render_ctr"),
@@ -405,7 +477,8 @@ def make_result(args, abi, build, rtdist, scene, plan, world, elapsed, render_ms
                              "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (nominal: a loop of nothing but independent "
                              "v_mul_f32 / v_add_f32 reaches 0.82-0.94 of it at a sustained 2.32-2.39 GHz -- tools/microbench/clock.hip, "
                              "profiles/r03_microbench_clock_and_issue.txt -- and v_fma / v_rcp / v_sqrt / 64-bit multiplies take more than one slot)"
-                             + ("; frames overlap on two streams here, so the kernel's event time includes time it shared the chip" if depth_pipe > 1 else "")
+                             + (f"; {depth_pipe} frames are in flight on their own streams, each on 1/{getattr(args, 'share_used', 1)} of the resident grid: a kernel's event time includes the time it shared the chip -- "
+                                "it is NOT the time of one frame alone, and `frac` is that of rank 0's kernel while the others ran beside it" if depth_pipe > 1 else "")
                              + ("; kernel figures are those of rank / device 0's rows" if world > 1 else "")},
         "cpu_baseline": cpu_baseline,
         **({"tail": tail} if tail else {}),
@@ -574,16 +647,23 @@ def main_single_process(args):
     path, W, H, spp, depth, skip_unknown = WORKLOADS[args.workload]
     scene = host.LoadedScene(os.path.join(ROOT, path), W, H, spp, depth, skip_unknown_primitives=skip_unknown)
     plan = rtdist.make_plan(H, W, n)
-    depth_pipe = args.pipeline if args.pipeline > 0 else 2
+    depth_pipe, share = (args.pipeline, max(args.share, 1)) if args.pipeline > 0 else frames_in_flight(args.workload)
+    if args.share > 0:
+        share = args.share
+    args.share_used = share
     parts = []                                               # parts[d] = that device's frame slots
     for d in range(n):
         with torch.cuda.device(devs[d]):
             slots = []
-            for _ in range(depth_pipe):
+            streams, info = concurrent_streams(torch, torch.device("cuda", devs[d]), depth_pipe * (n if rehearse else 1))
+            if d == 0:
+                args.stream_info = info
+            for k in range(depth_pipe):
                 ctx = device.Context(devs[d])
+                ctx.set_share(share)
                 ctx.set_scene(scene, scene.camera, scene.settings)
                 slots.append({"ctx": ctx, "local": torch.zeros((plan.max_rows, W), dtype=torch.int32, device=f"cuda:{devs[d]}"),
-                              "stream": torch.cuda.Stream(device=devs[d]), "ready": torch.cuda.Event()})
+                              "stream": streams[(d * depth_pipe + k) % len(streams)] if rehearse else streams[k], "ready": torch.cuda.Event()})
             parts.append({"slots": slots, "opt": plan.options_for(abi, d)})
     dev0 = torch.device("cuda", devs[0])
     stacked = [torch.empty((n * plan.max_rows, W), dtype=torch.int32, device=dev0) for _ in range(depth_pipe)]
@@ -687,7 +767,45 @@ def measure_one_shot(abi, device, scene):
     return out
 
 
-def measure_tail(abi, rtdist, slots, H, W, parts, steps, full_render_ms, torch, device, scene, full_resolve_ms=0.0):
+def measure_inflight(abi, rtdist, torch, device, scene, dev_index, H, W, spec, parts, steps):
+    """Frames in flight, measured: for every FxD of `spec`, F contexts (own workspace, output buffer, stream) whose persistent kernels each launch
+    1/D of the grid that fills the device; frames are enqueued round-robin, wall time per frame in steady state.  Full-size frames, and the frames
+    one of `parts` GPUs renders (strip part 0 of `parts`) when parts > 1."""
+    out = []
+    dev = torch.device("cuda", dev_index)
+    plans = [("full", abi.Options.make(), H)]
+    if parts > 1:
+        plan = rtdist.make_plan(H, W, parts)
+        plans.append((f"1/{parts}", plan.options_for(abi, 0), plan.max_rows))
+    for item in spec.split(","):
+        F, D = (int(t) for t in item.lower().split("x"))
+        ctxs = []
+        streams, info = concurrent_streams(torch, dev, F)
+        for k in range(F):
+            c = device.Context(dev_index)
+            c.set_share(D)
+            c.set_scene(scene, scene.camera, scene.settings)
+            ctxs.append({"ctx": c, "stream": streams[k], "local": torch.zeros((H, W), dtype=torch.int32, device=dev)})
+        rec = {"frames_in_flight": F, "grid_div": D, "distinct_queues": info["distinct"]}
+        for tag, o, _rows in plans:
+            for s in ctxs:                                           # warm: row tables, workspace
+                s["ctx"].render(s["local"].data_ptr(), None, o, s["stream"].cuda_stream)
+            torch.cuda.synchronize()
+            n = F * max(steps, 4)
+            t0 = time.perf_counter()
+            for i in range(n):
+                s = ctxs[i % F]
+                s["ctx"].render(s["local"].data_ptr(), None, o, s["stream"].cuda_stream)
+            torch.cuda.synchronize()
+            rec[f"ms_per_frame_{tag}"] = round((time.perf_counter() - t0) / n * 1e3, 4)
+            rec[f"checksum_{tag}"] = int(ctxs[-1]["local"].to(torch.int64).sum().item())
+        for s in ctxs:
+            s["ctx"].check(); s["ctx"].close()
+        out.append(rec)
+    return out
+
+
+def measure_tail(abi, rtdist, slots, H, W, parts, steps, full_render_ms, torch, device, scene, full_resolve_ms=0.0, workload=""):
     """What ONE of `parts` GPUs would run: strip part p of `parts` of the same image, timed on this GPU for every p.
     ideal = full-image kernel time / parts; the difference is the launch tail (waves draining their last paths).
     Then the same 1/P-image frames back to back on TWO streams (a context each), as bench.py runs them for N > 1: the next frame's
@@ -713,31 +831,34 @@ def measure_tail(abi, rtdist, slots, H, W, parts, steps, full_render_ms, torch, 
     worst_p = max(range(parts), key=lambda p: per_part[p][2])
     worst = per_part[worst_p]
     ideal = full_render_ms / parts
-    # two frames in flight
-    pair = list(slots[:2])
-    made = []
-    while len(pair) < 2:
-        c = device.Context(slot["local"].device.index)
-        c.set_scene(scene, scene.camera, scene.settings)
-        extra = {"ctx": c, "local": torch.zeros_like(slot["local"]), "stream": torch.cuda.Stream(device=slot["local"].device)}
-        pair.append(extra); made.append(extra)
-    if pair[0]["stream"].cuda_stream == pair[1]["stream"].cuda_stream or pair[0]["stream"].cuda_stream == 0:
-        pair[0] = dict(pair[0], stream=torch.cuda.Stream(device=slot["local"].device))
+    # frames in flight, as bench.py runs them for N > 1: F contexts + streams, each on 1 / share of the resident grid (mi355rt_context_set_share)
     o = plan.options_for(abi, worst_p)
-    for s in pair:
-        s["ctx"].render(s["local"].data_ptr(), None, o, s["stream"].cuda_stream)
-    torch.cuda.synchronize()
-    n2 = 2 * max(steps, 4)
-    t0 = time.perf_counter()
-    for i in range(n2):
-        s = pair[i & 1]
-        s["ctx"].render(s["local"].data_ptr(), None, o, s["stream"].cuda_stream)
-    torch.cuda.synchronize()
-    two = (time.perf_counter() - t0) / n2 * 1e3
-    for s in pair:
-        s["ctx"].check()
-    for e in made:
-        e["ctx"].close()
+    dev = slot["local"].device
+
+    def steady_state(F, share):
+        ctxs = []
+        streams, _info = concurrent_streams(torch, dev, F)
+        for k in range(F):
+            c = device.Context(dev.index)
+            c.set_share(share)
+            c.set_scene(scene, scene.camera, scene.settings)
+            ctxs.append({"ctx": c, "local": torch.zeros_like(slot["local"]), "stream": streams[k]})
+        for s in ctxs:
+            s["ctx"].render(s["local"].data_ptr(), None, o, s["stream"].cuda_stream)
+        torch.cuda.synchronize()
+        n = F * max(steps, 4)
+        t0 = time.perf_counter()
+        for i in range(n):
+            s = ctxs[i % F]
+            s["ctx"].render(s["local"].data_ptr(), None, o, s["stream"].cuda_stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        for s in ctxs:
+            s["ctx"].check(); s["ctx"].close()
+        return ms
+    two = steady_state(2, 1)                                   # round 4's form, kept for comparison: two full-size grids alternating
+    F, share = frames_in_flight(workload)
+    chosen = steady_state(F, share)
     ideal_step = (full_render_ms + full_resolve_ms) / parts
     return {"parts": parts, "strip_rows": plan.strip_rows, "ideal_render_ms": round(ideal, 4),
             "render_ms_max": round(max(x[0] for x in per_part), 4), "render_ms_mean": round(sum(x[0] for x in per_part) / parts, 4),
@@ -745,7 +866,10 @@ def measure_tail(abi, rtdist, slots, H, W, parts, steps, full_render_ms, torch, 
             "tail_efficiency": round(ideal / max(x[0] for x in per_part), 4),
             "two_streams": {"part": worst_p, "ms_per_frame": round(two, 4), "ideal_ms_per_frame": round(ideal_step, 4),
                             "efficiency": round(ideal_step / two, 4),
-                            "note": "1/P-image frames back to back on two streams (own context each), wall time per frame incl. resolve; ideal = (full-image render + resolve kernel ms) / P"},
+                            "note": "1/P-image frames back to back on two streams (own context each, full-size grids), wall time per frame incl. resolve; ideal = (full-image render + resolve kernel ms) / P"},
+            "frames_in_flight": {"part": worst_p, "frames": F, "share_of_device_per_frame": share, "ms_per_frame": round(chosen, 4), "ideal_ms_per_frame": round(ideal_step, 4),
+                                 "efficiency": round(ideal_step / chosen, 4),
+                                 "note": "what bench.py runs per GPU for N > 1: F frames in flight, each context told its share (mi355rt_context_set_share); steady-state wall time per 1/P-image frame"},
             "note": "one GPU renders strip part p of P of the image, every p in turn (no gather): an upper bound for P-GPU strong scaling"}
 
 

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 3u   /* 2: mi355rt_scene.textures, MI355RT_MAT_TEXTURE; 3: mi355rt_context_check exported, quads must carry a (near-)unit normal */
+#define MI355RT_ABI_VERSION 4u   /* 2: mi355rt_scene.textures, MI355RT_MAT_TEXTURE; 3: mi355rt_context_check exported, quads must carry a (near-)unit normal;
+                                    4: mi355rt_context_set_share exported; MI355RT_RNG_CTR draws from pcg4d (other numbers than versions 1-3, same distribution) */
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MI355RT_OK               0
@@ -232,6 +233,18 @@ int  mi355rt_rows_selected(const mi355rt_settings* settings, const mi355rt_optio
 int  mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* options_or_null,
                             void* d_out_packed_rgb, void* d_out_linear_rgb_or_null,
                             void* hip_stream, mi355rt_stats* stats_or_null);
+
+/* Frames in flight.  A render's path-tracing kernel is PERSISTENT: it launches as many workgroups as the device holds and each keeps claiming
+ * samples until the frame is done -- so the end of every launch is a tail in which ever fewer paths keep the device busy, and a second frame
+ * enqueued on another stream only trickles in as the first frame's workgroups retire.  For a large frame the tail is noise; for a small one -- the
+ * eighth of an 800 x 600 image that one of 8 GPUs renders, src/renderer.rs:87-103 sharded by rows -- it is a third of the launch.  A caller that
+ * renders a SEQUENCE of frames (an animation, progressive refinement, the bench) can hide it: keep F frames in flight, each on its own context
+ * (own workspace) and its own stream, and tell every one of these contexts that it has 1 / share_of of the device: its kernels then launch that
+ * fraction of the resident grid, F launches are co-resident, and a draining frame shares every SIMD with frames in their steady state.
+ * share_of = 1 (the default) is the whole device; valid: 1 .. 16.  F > 4 streams buy nothing (HIP multiplexes streams onto 4 hardware queues by
+ * default); F = 4 with share_of = 4 (mesh scenes with short walks: 2) measured best -- DESIGN.md section 7.  The image does not depend on it.
+ * Takes effect with the next render on the context.                                                                                     */
+int  mi355rt_context_set_share(mi355rt_context* ctx, uint32_t share_of);
 
 /* Completion check of the asynchronous form.  render_scene is infallible (src/renderer.rs:67): it either returns the whole image or
  * panics.  mi355rt_context_render with stats == NULL only ENQUEUES work, so a failure inside a kernel -- a wave of the wavefront

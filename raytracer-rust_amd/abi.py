@@ -5,7 +5,7 @@ the sizes against the values the C compiler reports (`mi355rt_host` exports them
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_IO, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 

@@ -126,6 +126,8 @@ struct mi355rt_context {
     int blocks_per_cu[KERNEL_VARIANTS] = {}, vgprs[KERNEL_VARIANTS] = {}, sgprs = 0;
     uint32_t variant = KERNEL_LOCKSTEP;  // chosen per scene in set_scene
     bool has_mesh = false;
+    uint32_t grid_div = 1;               // this context launches 1 / grid_div of the grid that fills the device: the caller keeps grid_div frames in flight, each on its own
+                                         // context and stream, so that their persistent kernels are co-resident (see render_samples; mi355rt_context_set_share)
     uint32_t guided_mult = 16;           // run length = (left in shard) / (guided_mult * waves per shard); 16 measured best at 1/8-image launches
     uint32_t inline_steps = 0;           // 1 when several meshes share the list (many rays miss a mesh's root box: teapot +5..12 %), 0 for a single mesh (semesterbild -10 % otherwise)
     uint32_t trav_min = 24;              // measured optimum 24-32 on semesterbild / teapot (tools/ab_kernel.py)
@@ -522,6 +524,7 @@ std::map<std::string, int> g_default_knobs;
 int apply_knob(mi355rt_context* ctx, const std::string& name, int v) {
     if (name == "kernel") { if (v < -1 || v >= (int)KERNEL_VARIANTS) return fail(MI355RT_ERR_INVALID, "knob kernel"); ctx->forced_variant = v; }
     else if (name == "inline_steps") { if (v < -1 || v > 8) return fail(MI355RT_ERR_INVALID, "knob inline_steps"); ctx->knob_inline_steps = v; }
+    else if (name == "grid_div") { if (v < 1 || v > 16) return fail(MI355RT_ERR_INVALID, "knob grid_div"); ctx->grid_div = (uint32_t)v; }
     else if (name == "guided_mult") { if (v < 1 || v > 64) return fail(MI355RT_ERR_INVALID, "knob guided_mult"); ctx->guided_mult = (uint32_t)v; }
     else if (name == "trav_min") { if (v < 1 || v > 64) return fail(MI355RT_ERR_INVALID, "knob trav_min"); ctx->trav_min = (uint32_t)v; }
     else if (name == "spin_idle") { if (v < 1) return fail(MI355RT_ERR_INVALID, "knob spin_idle"); ctx->spin_limit_idle = (uint32_t)v; }
@@ -819,7 +822,10 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         r.spp = (uint32_t)spp; r.inv_spp = 1.0f / (float)s1;                             // renderer.rs:85
         r.accum = (float*)d_accum; r.accum_load = s0 != 0 ? 1u : 0u;
         r.out_row = d_out_row; r.width = st.width; r.width_mul = p.width_mul; r.width_shift = p.width_shift;
-        const uint32_t resident = (uint32_t)(ctx->cu_count * ctx->blocks_per_cu[variant]);
+        // What fills the device, or this context's share of it: with F frames in flight (F contexts, F streams) each launch takes 1 / F of the wave slots,
+        // F launches are co-resident, and a frame whose last paths are draining shares every SIMD with frames in their steady state.  A full-size grid
+        // leaves the next frame's workgroups waiting for the draining frame's to retire one by one ("tail").
+        const uint32_t resident = std::max(1u, (uint32_t)(ctx->cu_count * ctx->blocks_per_cu[variant]) / ctx->grid_div);
         block_threads = block_threads_of(variant);
         std::vector<float> band_ms;
         for (uint32_t b = 0; b < n_bands; ++b) {
@@ -879,6 +885,15 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         stats->bands = n_bands; stats->grid_blocks = grid_blocks; stats->block_threads = block_threads;
     }
     return MI355RT_OK;
+}
+
+int mi355rt_context_set_share(mi355rt_context* ctx, uint32_t share_of) {
+    return guard([&]() -> int {
+    if (!ctx) return fail(MI355RT_ERR_INVALID, "ctx is null");
+    if (share_of < 1u || share_of > 16u) return fail(MI355RT_ERR_INVALID, "share_of must be 1 .. 16");
+    ctx->grid_div = share_of;
+    return MI355RT_OK;
+    });
 }
 
 int mi355rt_context_render(mi355rt_context* ctx, const mi355rt_options* opt, void* d_out_packed, void* d_out_linear,

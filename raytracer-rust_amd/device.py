@@ -13,7 +13,7 @@ from . import abi, build
 
 EXPORTS = ["mi355rt_render", "mi355rt_render_multi", "mi355rt_render_progressive", "mi355rt_context_create", "mi355rt_context_destroy", "mi355rt_context_set_scene",
            "mi355rt_rows_selected", "mi355rt_context_render", "mi355rt_context_render_progressive", "mi355rt_context_set_timing", "mi355rt_context_read_timing",
-           "mi355rt_context_check", "mi355rt_last_error", "mi355rt_abi_version"]
+           "mi355rt_context_check", "mi355rt_context_set_share", "mi355rt_last_error", "mi355rt_abi_version"]
 
 _lib = None
 _extra = {}
@@ -72,6 +72,8 @@ def _bind(so):
         L.mi355rt_context_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.mi355rt_context_check.restype = C.c_int
         L.mi355rt_context_check.argtypes = [C.c_void_p]
+        L.mi355rt_context_set_share.restype = C.c_int
+        L.mi355rt_context_set_share.argtypes = [C.c_void_p, C.c_uint32]
         L.mi355rt_debug_set_knob.restype = C.c_int
         L.mi355rt_debug_set_knob.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.mi355rt_debug_has_variant.restype = C.c_int
@@ -190,6 +192,11 @@ class Context:
     def set_knob(self, name, value):
         """Diagnostic knob of this context (before set_scene); see device.set_knob."""
         _check(self._L.mi355rt_debug_set_knob(self._h, name.encode(), int(value)), f"mi355rt_debug_set_knob({name})", self._L)
+
+    def set_share(self, share_of):
+        """mi355rt_context_set_share: this context is one of `share_of` contexts whose frames are in flight together (own stream each): its
+        persistent kernels launch 1 / share_of of the grid that fills the device."""
+        _check(self._L.mi355rt_context_set_share(self._h, int(share_of)), "mi355rt_context_set_share", self._L)
 
     def check(self):
         """mi355rt_context_check: waits for every render enqueued on this context and raises if a kernel left an image incomplete."""

@@ -1,0 +1,54 @@
+"""mi355rt_context_set_share (ABI 4): F frames in flight, each on its own context and stream, each persistent kernel on 1 / share of the resident
+grid, so that the launches are co-resident.  How many workgroups trace an image never changes it: every draw is addressed by (row, x, sample, ray)."""
+import numpy as np
+import pytest
+
+from conftest import load_for_both
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["cornell", "teapot", "veach"])
+def test_frames_in_flight_on_a_share_of_the_device_render_the_same_image(name, native, oracle_mod, abi):
+    import torch
+    host, device = native
+    sc = load_for_both(name, oracle_mod, host, width=160, height=96, spp=24, max_depth=12)
+    W, H = 160, 96
+    ref_p, ref_l, ref_st = device.render(sc, sc.camera, sc.settings, abi.Options.make())
+    part = abi.Options.make(strip_rows=3, n_parts=8, part=5)
+    rows = abi.rows_selected(H, part)
+    for frames, share in ((4, 4), (4, 2), (2, 2), (3, 16)):
+        slots = []
+        for _ in range(frames):
+            c = device.Context(0)
+            c.set_share(share)
+            c.set_scene(sc, sc.camera, sc.settings)
+            slots.append((c, torch.cuda.Stream(), torch.zeros((H, W), dtype=torch.int32, device="cuda"), torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")))
+        for rnd in range(3):                                              # frames enqueued back to back, nothing waited for in between
+            for i, (c, s, out, lin) in enumerate(slots):
+                c.render(out.data_ptr(), lin.data_ptr(), part if (rnd + i) % 2 else abi.Options.make(), s.cuda_stream)
+        torch.cuda.synchronize()
+        for i, (c, s, out, lin) in enumerate(slots):
+            c.check()
+            full = (2 + i) % 2 == 0                                        # what the LAST round rendered into this slot
+            got_p, got_l = out.cpu().numpy().view(np.uint32), lin.cpu().numpy()
+            if full:
+                assert np.array_equal(got_p, ref_p) and np.array_equal(got_l.view(np.uint32), ref_l.view(np.uint32)), (frames, share, i)
+            else:
+                n = len(rows)
+                assert np.array_equal(got_p[:n], ref_p[rows]) and np.array_equal(got_l[:n].view(np.uint32), ref_l[rows].view(np.uint32)), (frames, share, i)
+            st = c.render(out.data_ptr(), None, abi.Options.make(), s.cuda_stream, want_stats=True)
+            assert (st.samples, st.rays) == (ref_st.samples, ref_st.rays)
+            if share <= 4:
+                assert st.grid_blocks <= max(1, -(-ref_st.grid_blocks // share) + 1) or ref_st.grid_blocks < share, (st.grid_blocks, ref_st.grid_blocks, share)
+            c.close()
+
+
+def test_share_argument_is_checked(native, oracle_mod, abi):
+    host, device = native
+    c = device.Context(0)
+    for bad in (0, 17, 1 << 20):
+        with pytest.raises(device.RenderError, match="share_of"):
+            c.set_share(bad)
+    c.set_share(1); c.set_share(16)
+    c.close()

@@ -359,8 +359,11 @@ TESTS = [t_bytes, t_serial_pairs, t_birthday_spacings, t_collision, t_gap, t_pok
          t_hamming_indep, t_random_walk]
 
 
-def verdict(p):
-    e = min(p, 1.0 - p)
+TWO_SIDED = ("birthday_spacings_30bit", "collision_24bit", "hamming_weight_correlation", "unit_ball_acceptance")   # p = 2 min(left, right): only small values speak
+
+
+def verdict(p, name=""):
+    e = p if name in TWO_SIDED else min(p, 1.0 - p)                # a chi-square p-value near 1 is "too good to be true" and counts as well
     return "FAIL" if e < 1e-4 else "suspect" if e < 1e-3 else "ok"
 
 
@@ -387,8 +390,8 @@ def main():
     doc = {"log2n": args.log2n, "thresholds": {"FAIL": 1e-4, "suspect": 1e-3}, "generators": {}}
     for gen in args.gens.split(","):
         res = run(gen, args.log2n, args.orders.split(","))
-        fails = [(o, k, p) for o, d in res.items() for k, p in d["tests"].items() if verdict(p) == "FAIL"]
-        susp = [(o, k, p) for o, d in res.items() for k, p in d["tests"].items() if verdict(p) == "suspect"]
+        fails = [(o, k, p) for o, d in res.items() for k, p in d["tests"].items() if verdict(p, k) == "FAIL"]
+        susp = [(o, k, p) for o, d in res.items() for k, p in d["tests"].items() if verdict(p, k) == "suspect"]
         total = sum(len(d["tests"]) for d in res.values())
         doc["generators"][gen] = {"orders": res, "n_tests": total, "fail": [f"{o}/{k} p={p:.3g}" for o, k, p in fails], "suspect": [f"{o}/{k} p={p:.3g}" for o, k, p in susp]}
         print(f"{gen:12s} {total} p-values: {len(fails)} FAIL, {len(susp)} suspect" + ("".join(f"\n      FAIL    {o:6s} {k:28s} p = {p:.3g}" for o, k, p in fails[:12]))
