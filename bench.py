@@ -243,6 +243,10 @@ def main(argv=None):
             s["ctx"].render(s["local"].data_ptr(), None, opt, s["stream"].cuda_stream)     # enqueue only: no host sync inside
             image = rtdist.gather_image(s["local"].cpu() if rehearse else s["local"], plan, rank, always=use_dist)
 
+    if depth_pipe > 1:                                       # initialisation, not a step: every frame slot renders once, so that its radiance workspace is allocated
+        for s in slots:                                      # and its row table uploaded before anything is timed (with W < frames in flight the warm-up would not reach every slot)
+            s["ctx"].render(s["local"].data_ptr(), None, opt, s["stream"].cuda_stream)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -694,6 +698,11 @@ def main_single_process(args):
         for d in sorted(set(devs)):
             torch.cuda.synchronize(d)
 
+    for d in range(n):                                       # initialisation, not a step: every frame slot of every device renders once (workspace, row table)
+        for s in parts[d]["slots"]:
+            with torch.cuda.device(devs[d]):
+                s["ctx"].render(s["local"].data_ptr(), None, parts[d]["opt"], s["stream"].cuda_stream)
+    sync_all()
     for _ in range(args.warmup):
         step()
     sync_all()

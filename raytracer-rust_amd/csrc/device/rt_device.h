@@ -62,26 +62,14 @@ static_assert(sizeof(DevTri) == 48, "DevTri");
 
 struct DevCamera { float position[3], forward[3], right[3], true_up[3], half_width, half_height; };
 
-#ifndef MI355RT_BATCH_MIN
-#define MI355RT_BATCH_MIN 128
-#endif
-#ifndef MI355RT_BATCH_MAX
-#define MI355RT_BATCH_MAX 256
-#endif
 // 256 = one pixel's samples at the headline 256 spp: the lanes of a wave then share the camera ray and the first
 // hit, so whole accept blocks are skipped wave-wide (measured: 2048 -> 27.1 ms, 512 -> 26.1, 256 -> 25.8 on cornell).
-constexpr uint32_t BATCH_MIN = MI355RT_BATCH_MIN, BATCH_MAX = MI355RT_BATCH_MAX;   // paths a wave claims per global atomic (guided self-scheduling)
+constexpr uint32_t BATCH_MIN = 128, BATCH_MAX = 256;   // paths a wave claims per global atomic (guided self-scheduling)
 // The wavefront kernel claims runs of a FIXED 256 samples, aligned to 256 within the band: at the headline 256 spp a run is exactly
 // one pixel, at 64 spp four whole pixels, at 4096 spp a sixteenth of one -- the rays a workgroup holds stay coherent, its passes
 // less divergent.  Measured (profiles/r03_ab_wavefront_run_length.txt, 800x600x256): [128, 256] guided 28.96 / 17.76 ms
 // (semesterbild / teapot), fixed 256 28.63 / 17.34, fixed 512 28.95 / 17.30, [256, 512] 29.31 / 17.62, fixed 1024 30.5 / 17.4.
-#ifndef MI355RT_RUN_WAVEFRONT
-#define MI355RT_RUN_WAVEFRONT 256
-#endif
-#ifndef MI355RT_RUN_WAVEFRONT_MIN
-#define MI355RT_RUN_WAVEFRONT_MIN MI355RT_RUN_WAVEFRONT     // < RUN_WAVEFRONT: guided shrinking at the end of a shard (see guided_mult_wf in rt_api.cpp)
-#endif
-constexpr uint32_t RUN_WAVEFRONT = MI355RT_RUN_WAVEFRONT, RUN_WAVEFRONT_MIN = MI355RT_RUN_WAVEFRONT_MIN, RUN_LIMIT = 2048;
+constexpr uint32_t RUN_WAVEFRONT = 256, RUN_WAVEFRONT_MIN = RUN_WAVEFRONT, RUN_LIMIT = 2048;    // (MIN < RUN_WAVEFRONT would mean guided shrinking at the end of a shard)
 constexpr uint32_t BLOCK_THREADS = 256;         // lockstep kernels
 constexpr uint32_t BLOCK_THREADS_SM = 1024;     // state-machine kernels: 16 waves = 4 per SIMD = one workgroup per CU, sharing the LDS node copy
 constexpr uint32_t WORK_SHARDS = 8;            // one work counter per XCD (power of two)
@@ -115,7 +103,7 @@ struct RenderParams {
     uint32_t spp_mul, spp_shift, width_mul, width_shift;   // magic pairs for n / spp and n / width (n < 2^31)
     uint32_t trav_min;           // state-machine kernel: run BVH rounds while at least this many lanes are walking
     uint32_t inline_steps;       // state-machine kernel: box tests taken right at mesh setup (short walks skip the TRAV round trip)
-    uint32_t lds_nodes;          // state-machine kernel: nodes [0, lds_nodes) are read from the workgroup's LDS copy (<= LDS_NODE_CAP)
+    uint32_t lds_nodes;          // state-machine kernel (reference build): nodes [0, lds_nodes) are read from the workgroup's LDS copy (<= LDS_NODE_CAP)
     uint32_t spin_limit_idle;    // wavefront kernel: polls without progress before a wave gives up (SPIN_LIMIT_IDLE; a diagnostic hook lowers it)
     uint32_t spin_limit_entry;   // wavefront kernel: polls of one ring entry before a lane gives up (SPIN_LIMIT_ENTRY)
 };
@@ -199,46 +187,23 @@ int launch_resolve(const ResolveParams& p, void* stream);
 int launch_render_ref(const RefParams& p, void* stream);
 int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs, int* sgprs);
 bool render_ctr_variant_built(uint32_t variant);   // false for the retired mesh kernels in the product library (they live in the tests' -DMI355RT_REFS build)
-#ifndef MI355RT_WF_THREADS
-#define MI355RT_WF_THREADS 768
-#endif
-constexpr uint32_t BLOCK_THREADS_WF = MI355RT_WF_THREADS;   // wavefront kernel: waves per workgroup x 64 (A/B: fewer waves = more path slots per lane)
+constexpr uint32_t BLOCK_THREADS_WF = 768;                  // wavefront kernel: 12 waves per workgroup (measured against 8 / 10 / 14 / 16: rt_wavefront.h)
 // Wavefront kernel, LDS budget of one workgroup (rt_wavefront.h): control words, one ring per queue, the path slots, and -- in what is
 // left -- a copy of the first WF_LDS_NODES nodes of the (top-levels-first) node array.
-#ifndef MI355RT_WF_PATHS
-#define MI355RT_WF_PATHS 832                                // what fits beside seven rings (768 beside the eight there were: semesterbild +2.4 %, teapot +1.6 %)
-#endif
-#ifndef MI355RT_WF_RING
-#define MI355RT_WF_RING 1024
-#endif
-#ifndef MI355RT_WF_WGS_PER_CU
-#define MI355RT_WF_WGS_PER_CU 2
-#endif
-#ifndef MI355RT_WF_SLOT_WORDS
-#define MI355RT_WF_SLOT_WORDS 20
-#endif
-constexpr uint32_t WF_PATHS = MI355RT_WF_PATHS, WF_SLOT_WORDS = MI355RT_WF_SLOT_WORDS, WF_RING = MI355RT_WF_RING, WF_QUEUES = 7, WF_CTRL_WORDS = 32;
+// 832 slots: what fits beside seven rings (768 beside the eight there were: semesterbild +2.4 %, teapot +1.6 %); two workgroups per CU.
+// (A copy of the top of the node array in the rest of the budget was measured in round 3, profiles/r03_ab_wavefront_lds_nodes.txt: 348 nodes beside
+// 704 slots, or 2 110 nodes with one 16-wave workgroup per CU, run exactly as fast as the same geometry without the copy -- and every slot given up costs time.)
+constexpr uint32_t WF_PATHS = 832, WF_SLOT_WORDS = 20, WF_RING = 1024, WF_QUEUES = 7, WF_CTRL_WORDS = 32;
 constexpr uint32_t WF_FIXED_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
-constexpr uint32_t WF_LDS_BUDGET_WORDS = 163840u / 4u / MI355RT_WF_WGS_PER_CU;
+constexpr uint32_t WF_LDS_BUDGET_WORDS = 163840u / 4u / 2u;
 static_assert(WF_FIXED_WORDS <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budget");
-// Measured (profiles/r03_ab_wavefront_lds_nodes.txt): the copy buys nothing -- 348 nodes beside 704 slots, or 2 110 nodes with one
-// 16-wave workgroup per CU, run exactly as fast as the same geometry without the copy (the walk is bound by instruction issue at
-// low lane utilisation, not by node latency), and every slot given up for nodes costs time.  Default: no copy; -1 = fill the budget.
-#ifndef MI355RT_WF_LDS_NODES
-#define MI355RT_WF_LDS_NODES 0
-#endif
-constexpr uint32_t WF_LDS_NODES = MI355RT_WF_LDS_NODES >= 0 ? (uint32_t)MI355RT_WF_LDS_NODES : (WF_LDS_BUDGET_WORDS - WF_FIXED_WORDS) / 8u;    // 32-byte nodes
-static_assert(WF_FIXED_WORDS + 8u * WF_LDS_NODES <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budget (node copy)");
 constexpr uint32_t STATS_WORDS = 40;                         // u64 device counters per render: [0] paths, [1] rays, the rest diagnostic builds only
 inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB || variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_MESHFREE || variant == KERNEL_WAVEFRONT_NOMETAL_IDENT; }
 // The mesh-free form runs 2 x 16 waves per CU at 64 VGPRs (8 per SIMD): veach-mis 16.71 -> 16.09 ms; the forms with the BVH walk lose a third
 // there (42 spilled registers).  Waves per workgroup must be a multiple of 4: a workgroup's waves are dealt round-robin over the CU's
 // four SIMDs, and with 10, 13 or 14 of them the second workgroup no longer fits the per-SIMD wave budget (measured: +40 %; this also explains
 // round 2's "2 x 10 waves at 96 VGPRs" result).
-#ifndef MI355RT_WF_THREADS_MESHFREE
-#define MI355RT_WF_THREADS_MESHFREE 1024
-#endif
-constexpr uint32_t BLOCK_THREADS_WF_MESHFREE = MI355RT_WF_THREADS_MESHFREE;
+constexpr uint32_t BLOCK_THREADS_WF_MESHFREE = 1024;
 inline uint32_t block_threads_of(uint32_t variant) {
     return variant == KERNEL_WAVEFRONT_MESHFREE ? BLOCK_THREADS_WF_MESHFREE : is_wavefront(variant) ? BLOCK_THREADS_WF
          : (variant == KERNEL_STATE_MACHINE || variant == KERNEL_STATE_MACHINE_FIXAABB) ? BLOCK_THREADS_SM : BLOCK_THREADS;

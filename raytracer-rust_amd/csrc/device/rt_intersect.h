@@ -89,9 +89,7 @@ DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     float denom = dot(n, rd);
     const float num = pr->d[12] - dot(n, ro);
     float t;
-#ifndef MI355RT_AB_FULL_DIV
     if (FASTD && __ballot(fabsf(num) >= 0x1p100f) == 0ull) t = div_bounded(num, denom); else
-#endif
     t = num / denom;
     const bool candidate = !(fabsf(denom) < EPS) && !(t <= t_min || t >= c.t);
     // branch-free in the source: cornell 19.74 -> 19.61 ms, veach-mis +-0 with the 4-register candidate (the compiler still branches
@@ -236,8 +234,8 @@ DI void mesh_setup(PrimPtr pr, f3 ro_w, f3 rd_w, float t_max, MeshTrav& m, bool 
 // USE_LDS: nodes below `lds_count` are read from the workgroup's LDS copy (ds_read_b128), the rest from global memory.
 typedef float lds_v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) lds_v4f* lds_nodes_t;
-// USE_LDS: 0 = global memory only; 1 = the LDS copy when EVERY lane of the wave is below `lds_count` (wave-uniform choice);
-//          2 = chosen per lane (both loads may be in flight: LDS readers then also wait for the slowest global load of the wave).
+// USE_LDS (the reference build's state machine only; the product kernels read nodes from L1 / L2): 0 = global memory; 1 = the LDS copy when EVERY lane
+//          of the wave is below `lds_count` (a wave-uniform choice; a per-lane choice was measured too: the LDS readers then wait for the slowest global load).
 // SPEC (wavefront kernel's WALK stage): the walk does not stop at a hit leaf.  The leaf is left pending (leaf_a / leaf_b, and
 // `resume` = the node behind it) and the walk goes on with the unchanged best_t; a SECOND leaf while one is pending stalls the lane
 // in front of that leaf's node (it is visited again after the leaf phase).  See rt_wavefront.h for why this is exact.
@@ -248,7 +246,7 @@ DI void mesh_step(const float4* __restrict__ n4, lds_nodes_t lds, uint32_t lds_c
     // node): a per-lane choice would make the LDS readers wait for the other lanes' global loads (both paths fill the
     // same registers) and serialise the two latencies.  Whole array in LDS (semesterbild): always the LDS path.
     float4 q0, q1;
-    if (USE_LDS != 0 && (USE_LDS == 2 ? (m.node < lds_count) : (__ballot(m.node >= lds_count) == 0ull))) {
+    if (USE_LDS != 0 && __ballot(m.node >= lds_count) == 0ull) {
         lds_nodes_t lq = reinterpret_cast<lds_nodes_t>(reinterpret_cast<const __attribute__((address_space(3))) char*>(lds) + (m.node << 5));
         const lds_v4f l0 = lq[0], l1 = lq[1];
         q0 = make_float4(l0.x, l0.y, l0.z, l0.w); q1 = make_float4(l1.x, l1.y, l1.z, l1.w);

@@ -191,7 +191,7 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane, cons
 // Returns false when no lane is live afterwards and no work is left to deal.
 // DEFAULTS: give the per-lane temporaries default values.  The lockstep kernels run without (every value is read only on the
 // path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %), and since round 3 so does the wavefront
-// kernel (rt_wavefront.h, MI355RT_AB_WF_DEFAULTS); the reference build's state machine keeps them (its other lanes'
+// kernel (rt_wavefront.h); the reference build's state machine keeps them (its other lanes'
 // state must not be touched).  WIDE: Philox on 64-bit products (rt_rng.h).  DROP_PRIO: lower the wave's priority to 0 once the
 // fresh samples are dealt (the caller raised it for the memory-bound half of the iteration).  Q0_IN_HIT: see struct Hit.
 // FASTN: see normalized() (rt_math.h).  TRY1: try 1 of the unit-ball draw comes from a second Philox block drawn in the lane itself, right after the
@@ -209,11 +209,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
     if (DEFAULTS) q0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         f3 term = mk(0.f, 0.f, 0.f); bool fin = false;
-#ifdef MI355RT_AB_NO_SKY
-        if (!hit) { term = mk(P.miss[0], P.miss[1], P.miss[2]); fin = true; }
-#else
         if (!hit) { term = miss_colour(P.sky, P.sky_w, P.sky_h, P.miss, ps.rd); fin = true; }   // renderer.rs:38-63
-#endif
         else {
             if constexpr (Q0_IN_HIT) q0 = h.q0;                                              // (finish_hit read it with the hit record)
             else q0 = reinterpret_cast<const float4*>(P.mats + (h.mat_ff & 0x7FFFFFFFu))[0];
@@ -315,46 +311,22 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
 // Register budget per kernel, as waves per SIMD (A/B: tools/ab.py).  The lockstep kernel is VALU-issue bound
 // and gains from 7 waves/SIMD (72 VGPRs) even with a few spills; the state-machine kernel keeps its hot BVH state in
 // registers and loses when capped.
-#ifndef MI355RT_TRAV_BIAS
-#define MI355RT_TRAV_BIAS 2
-#endif
-#ifndef MI355RT_OCC_LOCKSTEP
+#define MI355RT_TRAV_BIAS 2                                 // (reference build's state machine)
 #define MI355RT_OCC_LOCKSTEP 6                               // general mesh-free kernel, veach-mis 64 spp.  Round 1: 4 -> 6.46 ms, 5 -> 6.03, 6 -> 5.79,
                                                             // 7 -> 5.73.  After the instruction diet: 7 -> 4.94, 6 -> 4.88, and with the cube hit point
                                                             // carried (3 more registers): 7 -> 5.03 (spills), 6 -> 4.81, 5 -> 5.04
-#endif
-#if MI355RT_OCC_LOCKSTEP > 0
 #define MI355RT_OCC_LS __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_LOCKSTEP, MI355RT_OCC_LOCKSTEP)))
-#else
-#define MI355RT_OCC_LS
-#endif
-#ifndef MI355RT_OCC_LOCKSTEP_SIMPLE
-#define MI355RT_OCC_LOCKSTEP_SIMPLE 7
-#endif
-#define MI355RT_OCC_SIMPLE __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_LOCKSTEP_SIMPLE, MI355RT_OCC_LOCKSTEP_SIMPLE)))
-#ifndef MI355RT_OCC_SM
-#define MI355RT_OCC_SM 4
-#endif
-#if MI355RT_OCC_SM > 0
-#define MI355RT_OCC_SMK __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_SM, MI355RT_OCC_SM)))
-#else
-#define MI355RT_OCC_SMK
-#endif
+#define MI355RT_OCC_SIMPLE __attribute__((amdgpu_waves_per_eu(7, 7)))
+#define MI355RT_OCC_SMK __attribute__((amdgpu_waves_per_eu(4, 4)))      // (reference build's state machine)
 
 // ===================================================================================================
 // k_render_ctr<HAS_MESH> -- persistent, path-regenerating wave64 path tracer, lockstep form: every live lane
 // traces one full ray per loop iteration.  Used for scenes whose top level has no mesh (cornell, veach-mis):
 // all lanes walk the same primitive list, so the iteration is divergence-free up to the hit tests.
 // ===================================================================================================
-#ifndef MI355RT_GENERAL_CARRY_PO
-#define MI355RT_GENERAL_CARRY_PO true                       // the general mesh-free kernel carries the cube hit point too (see hit_scene): pays at 80 VGPRs
-#endif
-#ifndef MI355RT_AB_FASTN_LS
-#define MI355RT_AB_FASTN_LS true
-#endif
-#ifndef MI355RT_AB_TRY1_SIMPLE
-#define MI355RT_AB_TRY1_SIMPLE 1
-#endif
+// The lockstep kernels' forms (each measured against its alternative; docs/kernels/lockstep_round3.md): the candidate carries the cube's object-space hit
+// point (also in the general kernel: pays at 80 VGPRs); the short reciprocal / square root / division of rt_math.h; in the Lambert-only kernel ONE try of the
+// unit-ball draw in the lane itself before the cooperative rounds (0 tries: +1.9 %, 2 tries: +-0 with pcg4d, +23 % with Philox: profiles/r05/ab_counter_generator.txt).
 template <bool HAS_MESH, uint32_t MATS>
 DI void render_ctr_lockstep(const RenderParams& P) {
     constexpr bool SIMPLE = (MATS & ~MATS_LAMBERT) == 0u;
@@ -378,9 +350,9 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         // wave whose loads can then be in flight under the others' arithmetic.  cornell 16.49 -> 15.82 ms, veach-mis on these kernels -1.7 %;
         // priority 2 or 3 measure the same; keeping it through Philox (15.96) or only over the walk (16.10-16.17) gains less.
         __builtin_amdgcn_s_setprio(1);
-        if (live) hit = hit_scene<HAS_MESH, SIMPLE || MI355RT_GENERAL_CARRY_PO>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
+        if (live) hit = hit_scene<HAS_MESH, true>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, MI355RT_AB_FASTN_LS, SIMPLE ? MI355RT_AB_TRY1_SIMPLE : 0>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, /* FASTN */ true, /* TRY1 */ SIMPLE ? 1 : 0>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths
@@ -405,15 +377,12 @@ DI void render_ctr_lockstep(const RenderParams& P) {
     if (lane == 0 && P.stats) { atomicAdd(&P.stats[0], (unsigned long long)wp); atomicAdd(&P.stats[1], (unsigned long long)wr); }
 }
 
-#ifndef MI355RT_AB_LS_MATS
-#define MI355RT_AB_LS_MATS MATS_ALL
-#endif
 // Entry points: one body, instantiated per scene class so that each gets its own register budget.
 //   k_render_ctr_nomesh  any materials, no mesh in the list            (veach-mis)                7 waves/SIMD
 //   k_render_ctr_simple  Lambertian/Emissive/Null only, no mesh        (cornell: -3 % vs nomesh)   7 waves/SIMD
 //   k_render_ctr_nospec  no metal, no dielectric, no mesh              (veach-mis: -2.5 % vs nomesh) 7 waves/SIMD
 //   k_render_ctr_mesh    lockstep with the per-lane BVH walk inlined   (A/B reference for the state machine)
-__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_nomesh(const RenderParams P) { render_ctr_lockstep<false, MI355RT_AB_LS_MATS>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_nomesh(const RenderParams P) { render_ctr_lockstep<false, MATS_ALL>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_simple(const RenderParams P) { render_ctr_lockstep<false, MATS_LAMBERT>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_nospec(const RenderParams P) { render_ctr_lockstep<false, MATS_NO_SPECULAR>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_render_ctr_mesh(const RenderParams P) { render_ctr_lockstep<true, MATS_ALL>(P); }

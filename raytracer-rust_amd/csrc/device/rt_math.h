@@ -60,14 +60,10 @@ DI float len(f3 a) { return sqrtf(len2(a)); }                                   
 // profiles/r03_microbench_reciprocal.txt: the only inputs where the two differ are denormals and |x| >= 2^126, whose reciprocal is a
 // denormal) -- at about half the issue slots (7.5 instead of 14.8).  For callers that can bound their argument.
 DI float recip_normal_range(float x) {
-#ifdef MI355RT_AB_FULL_RECIP
-    return 1.0f / x;
-#else
     float r = __builtin_amdgcn_rcpf(x);
     const float e = __builtin_fmaf(-x, r, 1.0f);
     r = __builtin_fmaf(e, r, r);
     return __builtin_amdgcn_div_fixupf(r, x, 1.0f);
-#endif
 }
 // (the length is a square root: at most sqrt(FLT_MAX) = 1.8e19 < 2^126 or +inf / NaN, and at least EPS here)
 // FASTN: with length_for_normalize() and recip_normal_range().  Same bits either way; the kernels of mesh-free lists gain 2-3 % from it
@@ -100,14 +96,12 @@ DI float div_by_rn(float a, float b, float r) {
 // NaN components are ignored by the test and give NaN either way.  (The ballot covers the lanes that are active at the call.)
 template <bool FASTR>
 DI void recip3(float x, float y, float z, float& ix, float& iy, float& iz) {
-#ifndef MI355RT_AB_FULL_RECIP3
     if constexpr (FASTR) {
     const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
     const float mx = fmaxf(fmaxf(ax, ay), az);
     const float mn = fminf(fminf(ax == 0.0f ? 1.0f : ax, ay == 0.0f ? 1.0f : ay), az == 0.0f ? 1.0f : az);
     if (__ballot((mn < 0x1p-126f) || (mx >= 0x1p126f)) == 0ull) { ix = recip_normal_range(x); iy = recip_normal_range(y); iz = recip_normal_range(z); return; }
     }
-#endif
     ix = 1.0f / x; iy = 1.0f / y; iz = 1.0f / z;
 }
 
@@ -126,9 +120,7 @@ DI float length_for_normalize(float x) {
 }
 template <bool FASTN = false>
 DI f3 normalized(f3 a) {                                                          // :37-44
-#ifndef MI355RT_AB_FULL_SQRT
     if constexpr (FASTN) { const float l = length_for_normalize(len2(a)); if (l < EPS) return a; return a * recip_normal_range(l); }
-#endif
     const float l = len(a); if (l < EPS) return a; return a * (FASTN ? recip_normal_range(l) : 1.0f / l);
 }
 DI bool near_zero(f3 a) { const float S = 1e-8f; return fabsf(a.x) < S && fabsf(a.y) < S && fabsf(a.z) < S; }  // :63-66

@@ -13,13 +13,7 @@ DI float u32_to_f01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f);
 // rand's `random_range(-1.0..1.0)`: (value1_2 - 1.0) * 2.0 + -1.0 with value1_2 = the 23 high bits as the mantissa of a float in [1, 2).
 // Every step of that is exact, so the result is k * 2^-22 - 1 for k = w >> 9 -- which is also, exactly, the float in [2, 4) with mantissa k
 // minus 3: three instructions instead of five, the same bits for all 2^23 values of k (tests/test_oracle_rng.py checks them all).
-DI float u32_to_range11(uint32_t w) {
-#ifdef MI355RT_AB_RANGE11_LONG
-    float v12 = __uint_as_float((w >> 9) | 0x3F800000u); float v01 = v12 - 1.0f; return v01 * 2.0f + -1.0f;
-#else
-    return __uint_as_float((w >> 9) | 0x40000000u) - 3.0f;
-#endif
-}
+DI float u32_to_range11(uint32_t w) { return __uint_as_float((w >> 9) | 0x40000000u) - 3.0f; }
 
 // Philox4x32-R (Salmon et al., SC'11): counter-based, no state.  R x (2 x 32x32->64 multiplies + 4 xor + 2 add).
 // WIDE: one 64-bit product per multiplier -- v_mad_u64_u32 issues like ONE v_mul_hi_u32 (2.1 add slots, tools/microbench/int_mul.hip)

