@@ -4,7 +4,7 @@
   python3 tools/pmc_collect.py --out gpurun_out/pmc [--workloads W1 W2 ...]
 
 For every workload and every counter group one `rocprofv3 --pmc <group> -- python3 bench.py --steps 1 --warmup 1
---cpu-seconds 0 --workload W` pass (counters only: never together with --stats / trace domains; FETCH_SIZE and
+--cpu-seconds 0 --no-one-shot --workload W` pass (counters only: never together with --stats / trace domains; FETCH_SIZE and
 WRITE_SIZE in passes of their own, MI355X_MICROARCH.md "rocprofv3 PMC slots").  One bench run = 3 full renders
 (warm-up, timed step, counter step), each `bands` dispatches of the path-tracing kernel; the summary divides the
 dispatch totals by 3, so every figure is PER STEP (one full render, all bands).
@@ -75,7 +75,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     doc = {"kernel_hash": build.kernel_hash(), "collected_unix": int(time.time()),
-           "command": "rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --workload <W>",
+           "command": "rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --no-one-shot --workload <W>",
            "groups": GROUPS, "per": "step (one full render of the workload = all workspace bands)", "workloads": {}}
     failed = []
     for wl in args.workloads:
@@ -84,7 +84,7 @@ def main():
         for i, grp in enumerate(GROUPS):
             pdir = os.path.join(wdir, f"pass{i}")
             cmd = ["timeout", "-k", "10", str(args.pass_timeout), "rocprofv3", "--pmc", *grp, "--output-format", "csv", "-d", pdir, "--",
-                   "python3", os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--workload", wl]
+                   "python3", os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--no-one-shot", "--workload", wl]
             t0 = time.time()
             with open(os.path.join(args.out, f"{wl}.pass{i}.log"), "w") as log:
                 rc = subprocess.call(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
