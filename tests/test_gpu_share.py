@@ -51,3 +51,20 @@ def test_share_argument_is_checked(native, oracle_mod, abi):
             c.set_share(bad)
     c.set_share(1); c.set_share(16)
     c.close()
+
+
+def test_bench_picks_streams_that_really_overlap(native):
+    """bench.py gives every frame in flight a stream of its own hardware-queue class (HIP multiplexes streams onto 4 hardware queues in an order the
+    caller cannot see; two of four consecutive streams can share one: profiles/r05/stream_queue_probe.txt).  The probe must find 4 classes on an MI355X
+    with the default runtime settings, and the streams it returns must be pairwise different."""
+    import importlib
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    streams, info = bench.concurrent_streams(torch, torch.device("cuda", 0), 4)
+    assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4
+    assert info["method"].startswith("torch.cuda._sleep") and info["queue_classes_found"] >= 4 and info["distinct"] == 4, info
+    again, _ = bench.concurrent_streams(torch, torch.device("cuda", 0), 2)          # cached per device: the same classes
+    assert [s.cuda_stream for s in again] == [s.cuda_stream for s in streams[:2]]
