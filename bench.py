@@ -219,7 +219,8 @@ def main(argv=None):
     # never share scratch memory.  The scene is resident in HBM in every slot from here on.
     slots = []
     streams, stream_info = ([torch.cuda.current_stream()], None) if depth_pipe == 1 else concurrent_streams(torch, dev, depth_pipe)
-    args.stream_info = stream_info
+    depth_pipe, share, stream_info = fit_frames_to_queues(depth_pipe, share, stream_info, auto=args.pipeline <= 0 and args.share <= 0)
+    args.stream_info = stream_info; args.share_used = share
     for i in range(depth_pipe):
         ctx = device.Context(local_rank)
         ctx.set_share(share)
@@ -401,6 +402,21 @@ def concurrent_streams(torch, dev, want, pool=24):
     classes, rest, info = _STREAM_CLASSES[key]
     picked = (classes + rest)[:want]
     return picked, dict(info, wanted=want, distinct=min(want, len(classes)))
+
+
+def fit_frames_to_queues(frames, share, info, auto=True):
+    """Frames in flight that share a hardware queue serialise -- four quarter-grid kernels on three queues leave a third of the device idle (0.68 of
+    ideal instead of 0.95, profiles/r05/stream_queue_probe.txt).  When the probe found fewer queue classes than frames were wanted (another runtime
+    configuration, other tenants of the queues), the automatic choice falls back to as many frames as there are classes, each on that share of the
+    device; an explicit --pipeline / --share is left as typed."""
+    if not info or not auto:
+        return frames, share, info
+    found = info.get("queue_classes_found")
+    if found is not None and 1 <= found < frames:
+        info = dict(info, reduced_from=[frames, share], why=f"only {found} hardware-queue class(es) found")
+        frames = found
+        share = min(share, frames)
+    return frames, share, info
 
 
 def product_modules():
@@ -661,7 +677,9 @@ def main_single_process(args):
             slots = []
             streams, info = concurrent_streams(torch, torch.device("cuda", devs[d]), depth_pipe * (n if rehearse else 1))
             if d == 0:
-                args.stream_info = info
+                if not rehearse:
+                    depth_pipe, share, info = fit_frames_to_queues(depth_pipe, share, info, auto=args.pipeline <= 0 and args.share <= 0)
+                args.stream_info = info; args.share_used = share
             for k in range(depth_pipe):
                 ctx = device.Context(devs[d])
                 ctx.set_share(share)

@@ -54,3 +54,17 @@ def test_cpu_thread_count_respects_an_override(monkeypatch):
     monkeypatch.delenv("MI355RT_CPU_THREADS")
     n, why = bench.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1) and "affinity" in why
+
+
+def test_frames_in_flight_fall_back_to_the_queue_classes_that_exist():
+    bench = importlib.import_module("bench")
+    ok = {"queue_classes_found": 4, "distinct": 4}
+    assert bench.fit_frames_to_queues(4, 4, ok) == (4, 4, ok)
+    f, s, info = bench.fit_frames_to_queues(4, 4, {"queue_classes_found": 3, "distinct": 3})
+    assert (f, s) == (3, 3) and info["reduced_from"] == [4, 4]
+    f, s, info = bench.fit_frames_to_queues(4, 2, {"queue_classes_found": 1, "distinct": 1})
+    assert (f, s) == (1, 1)
+    unprobed = {"queue_classes_found": None}
+    assert bench.fit_frames_to_queues(4, 4, unprobed) == (4, 4, unprobed)                      # nothing known: as chosen
+    assert bench.fit_frames_to_queues(4, 4, {"queue_classes_found": 2}, auto=False)[:2] == (4, 4)   # typed by the user: as typed
+    assert bench.fit_frames_to_queues(1, 1, None) == (1, 1, None)
