@@ -194,7 +194,7 @@ static int report_device_error(mi355rt_context* ctx, bool this_render) {
     ctx->err_reported = count;
     static const char* const kernel_names[KERNEL_VARIANTS] = {"k_render_ctr_nomesh", "k_render_ctr_mesh", "k_render_ctr_sm", "k_render_ctr_simple", "k_render_ctr_sm_fixaabb",
         "(retired)", "(retired)", "k_render_ctr_wf", "k_render_ctr_wf_fixaabb", "k_render_ctr_nospec", "k_render_ctr_wf_nometal", "k_render_ctr_wf_meshfree",
-        "k_render_ctr_wf_nometal_ident"};
+        "k_render_ctr_wf_nometal_ident", "k_render_ctr_wf_nometal_shallow"};
     static const struct { uint32_t bit; const char* what; } waits[] = {
         {WAIT_WF_IDLE, "idle: no progress in the workgroup"}, {WAIT_WF_RING, "ring entry: a reserved ticket was never written, or an entry never emptied"},
         {WAIT_WF_FOLLOWED, "waves that followed their workgroup's error flag out"}};
@@ -404,7 +404,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     if (sc->n_meshes && (!sc->meshes || !sc->nodes || !sc->triangles || (!sc->tri_indices && sc->n_tri_indices))) return fail(MI355RT_ERR_INVALID, "mesh arrays are null");
     { int rc = flatten_meshes(sc, nodes, tris, mesh_roots); if (rc) return rc; }
     std::vector<DevPrim> prims(sc->n_primitives);
-    bool all_meshes_identity = true;
+    bool all_meshes_identity = true, all_meshes_shallow = true;
     for (uint32_t i = 0; i < sc->n_primitives; ++i) {
         const mi355rt_primitive& p = sc->primitives[i];
         DevPrim& d = prims[i];
@@ -437,6 +437,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
                 if (p.mesh >= sc->n_meshes) return fail(MI355RT_ERR_INVALID, "primitive mesh index");
                 d.node_begin = mesh_roots[p.mesh];
                 all_meshes_identity = all_meshes_identity && xform_is_identity(w2o);
+                all_meshes_shallow = all_meshes_shallow && sc->meshes[p.mesh].node_count <= WF_SHALLOW_NODES;
             }
         } else {
             std::memcpy(d.d, p.data, 32 * sizeof(float));
@@ -489,7 +490,9 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     // the kinds a scene does not have are compiled out -- they set the register peak.  The library reads NO environment
     // variables; the diagnostic hook mi355rt_debug_set_knob("kernel", v) may name another variant this library was built with.
     // ... and, where the meshes are all untransformed (OBJ data in world space: teapot), the instantiation whose mesh_setup skips the matrix products.
-    if (has_mesh) ctx->variant = covers(KERNEL_WAVEFRONT_NOMETAL) ? (all_meshes_identity ? KERNEL_WAVEFRONT_NOMETAL_IDENT : KERNEL_WAVEFRONT_NOMETAL) : KERNEL_WAVEFRONT;
+    // ... and, for transformed meshes whose trees are all small (semesterbild), the instantiation with the shorter WALK rounds (rt_wavefront.h).
+    if (has_mesh) ctx->variant = covers(KERNEL_WAVEFRONT_NOMETAL) ? (all_meshes_identity ? KERNEL_WAVEFRONT_NOMETAL_IDENT : all_meshes_shallow ? KERNEL_WAVEFRONT_NOMETAL_SHALLOW : KERNEL_WAVEFRONT_NOMETAL)
+                                                                  : KERNEL_WAVEFRONT;
     else {
         // Mesh-free lists run on a lockstep kernel -- unless the shading step diverges EXPENSIVELY: a rough conductor (ln, atan, two
         // sin_cos, the conductor's Fresnel term: ~400 instructions) next to another scattering material.  In lockstep a wave pays that branch
@@ -506,7 +509,7 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         const bool mesh_free_only = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_MESHFREE;
         const bool selectable = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || v == KERNEL_WAVEFRONT ||
                                 v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_NOMETAL || v == KERNEL_WAVEFRONT_MESHFREE ||
-                                v == KERNEL_WAVEFRONT_NOMETAL_IDENT;   // (the _FIXAABB forms follow options.flags)
+                                v == KERNEL_WAVEFRONT_NOMETAL_IDENT || v == KERNEL_WAVEFRONT_NOMETAL_SHALLOW;   // (the _FIXAABB forms follow options.flags; _SHALLOW is only a tuning: any tree is walked correctly)
         const bool ok = render_ctr_variant_built(v) && selectable && covers(v) && !(mesh_free_only && has_mesh) &&
                         !(v == KERNEL_WAVEFRONT_NOMETAL_IDENT && !(has_mesh && all_meshes_identity));     // (that form ASSUMES untransformed meshes)
         if (ok) ctx->variant = v;

@@ -128,8 +128,10 @@ enum : uint32_t {
     KERNEL_WAVEFRONT_NOMETAL = 10,   // KERNEL_WAVEFRONT without the metal branch (teapot, semesterbild)
     KERNEL_WAVEFRONT_MESHFREE = 11,  // the wavefront for lists WITHOUT a mesh, no metal / dielectric: material-sorted SHADE passes for scenes whose materials diverge (veach-mis)
     KERNEL_WAVEFRONT_NOMETAL_IDENT = 12,   // KERNEL_WAVEFRONT_NOMETAL for lists whose meshes are all untransformed (teapot): mesh_setup without its matrix products
-    KERNEL_VARIANTS = 13
+    KERNEL_WAVEFRONT_NOMETAL_SHALLOW = 13, // KERNEL_WAVEFRONT_NOMETAL for lists whose meshes all have small trees (semesterbild): WALK passes of 3 x 6 instead of 3 x 8 box tests
+    KERNEL_VARIANTS = 14
 };
+constexpr uint32_t WF_SHALLOW_NODES = 4096;      // "small tree": at most this many BVH nodes per mesh (a median-split tree of <= ~6 000 triangles, depth <= 11)
 // Material sets (bit k = kind MI355RT_MAT_k may occur) the kernels are instantiated for; set_scene picks, per kernel family, the
 // most pruned instantiation whose set covers the scene's materials.  The branches compiled out set the register peak.
 constexpr uint32_t MATBIT(uint32_t kind) { return 1u << kind; }
@@ -142,7 +144,7 @@ constexpr uint32_t MATS_NO_METAL = MATS_ALL & ~MATBIT(MI355RT_MAT_METAL);
 constexpr uint32_t MATS_NO_SPECULAR = MATS_ALL & ~(MATBIT(MI355RT_MAT_METAL) | MATBIT(MI355RT_MAT_DIELECTRIC));
 inline uint32_t mats_of_variant(uint32_t variant) {
     return variant == KERNEL_LOCKSTEP_SIMPLE ? MATS_LAMBERT : (variant == KERNEL_LOCKSTEP_NOSPEC || variant == KERNEL_WAVEFRONT_MESHFREE) ? MATS_NO_SPECULAR
-         : (variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_NOMETAL_IDENT) ? MATS_NO_METAL : MATS_ALL;
+         : (variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_NOMETAL_IDENT || variant == KERNEL_WAVEFRONT_NOMETAL_SHALLOW) ? MATS_NO_METAL : MATS_ALL;
 }
 
 struct ResolveParams {
@@ -198,7 +200,7 @@ constexpr uint32_t WF_FIXED_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + W
 constexpr uint32_t WF_LDS_BUDGET_WORDS = 163840u / 4u / 2u;
 static_assert(WF_FIXED_WORDS <= WF_LDS_BUDGET_WORDS, "wavefront kernel LDS budget");
 constexpr uint32_t STATS_WORDS = 40;                         // u64 device counters per render: [0] paths, [1] rays, the rest diagnostic builds only
-inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB || variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_MESHFREE || variant == KERNEL_WAVEFRONT_NOMETAL_IDENT; }
+inline bool is_wavefront(uint32_t variant) { return variant == KERNEL_WAVEFRONT || variant == KERNEL_WAVEFRONT_FIXAABB || variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_MESHFREE || variant == KERNEL_WAVEFRONT_NOMETAL_IDENT || variant == KERNEL_WAVEFRONT_NOMETAL_SHALLOW; }
 // The mesh-free form runs 2 x 16 waves per CU at 64 VGPRs (8 per SIMD): veach-mis 16.71 -> 16.09 ms; the forms with the BVH walk lose a third
 // there (42 spilled registers).  Waves per workgroup must be a multiple of 4: a workgroup's waves are dealt round-robin over the CU's
 // four SIMDs, and with 10, 13 or 14 of them the second workgroup no longer fits the per-SIMD wave budget (measured: +40 %; this also explains

@@ -552,6 +552,7 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
         case KERNEL_WAVEFRONT_MESHFREE: hipLaunchKernelGGL(k_render_ctr_wf_meshfree, dim3(grid_blocks), dim3(BLOCK_THREADS_WF_MESHFREE), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_NOMETAL: hipLaunchKernelGGL(k_render_ctr_wf_nometal, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_NOMETAL_IDENT: hipLaunchKernelGGL(k_render_ctr_wf_nometal_ident, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
+        case KERNEL_WAVEFRONT_NOMETAL_SHALLOW: hipLaunchKernelGGL(k_render_ctr_wf_nometal_shallow, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT:       hipLaunchKernelGGL(k_render_ctr_wf, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_FIXAABB: hipLaunchKernelGGL(k_render_ctr_wf_fixaabb, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
 #ifdef MI355RT_REFS
@@ -587,6 +588,7 @@ int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs,
                    : variant == KERNEL_LOCKSTEP_NOSPEC ? reinterpret_cast<const void*>(k_render_ctr_nospec)
                    : variant == KERNEL_WAVEFRONT_NOMETAL ? reinterpret_cast<const void*>(k_render_ctr_wf_nometal)
                    : variant == KERNEL_WAVEFRONT_NOMETAL_IDENT ? reinterpret_cast<const void*>(k_render_ctr_wf_nometal_ident)
+                   : variant == KERNEL_WAVEFRONT_NOMETAL_SHALLOW ? reinterpret_cast<const void*>(k_render_ctr_wf_nometal_shallow)
                    : variant == KERNEL_WAVEFRONT_MESHFREE ? reinterpret_cast<const void*>(k_render_ctr_wf_meshfree)
                    : variant == KERNEL_WAVEFRONT ? reinterpret_cast<const void*>(k_render_ctr_wf)
 #ifdef MI355RT_REFS

@@ -186,7 +186,7 @@ struct WfQueues {
 // MESH_IDENT: every mesh of the list is untransformed (the host picks this instantiation then): see ray_nonzero_finite() in rt_intersect.h.
 // INLINE_STEPS: box tests of a walk that TOP runs itself when at least half the wave is inside the root box (8; 12 measured better for the deep trees of the
 // scene the MESH_IDENT form serves: teapot -0.7 %, and worse for semesterbild's shallower one: +0.8 %).
-template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true, bool MESH_IDENT = false, int INLINE_STEPS = 8>
+template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true, bool MESH_IDENT = false, int INLINE_STEPS = 8, int WF_ROUNDS = 3, int WF_STEPS = 8>
 DI void render_ctr_wavefront(const RenderParams& P) {
     typedef SlotIO Slot;
     constexpr uint32_t WF_PATHS = HAS_MESH ? mi355rt::WF_PATHS : WF_PATHS_MESHFREE, WF_SLOT_WORDS = HAS_MESH ? mi355rt::WF_SLOT_WORDS : 16u;
@@ -218,10 +218,9 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #else
 #define MI355RT_WFCOUNT(i, n) do {} while (0)
 #endif
-    // WALK geometry: WF_ROUNDS rounds of WF_STEPS box tests + the pending leaves per pass.  Measured (ms, semesterbild / teapot at 64 spp): 1x8 11.8 / 7.5,
-    // 2x8 10.7 / 6.6, 3x8 10.4 / 6.4, 4x8 10.4 / 6.3, 8x8 10.7 / 6.6, 3x12 10.7 / 6.4; per scene in round 4: 4x6 -0.8 % / +2.8 %.  The box test is unrolled
+    // WALK geometry (template arguments): WF_ROUNDS rounds of WF_STEPS box tests + the pending leaves per pass.  Measured (ms, semesterbild / teapot at 64 spp): 1x8 11.8 / 7.5,
+    // 2x8 10.7 / 6.6, 3x8 10.4 / 6.4, 4x8 10.4 / 6.3, 8x8 10.7 / 6.6, 3x12 10.7 / 6.4; per scene class since round 5: see k_render_ctr_wf_nometal_shallow.  The box test is unrolled
     // WF_STEPS times (the kernel is 47 KB of code; two CUs share a 64 KB instruction cache).
-    constexpr int WF_ROUNDS = 3, WF_STEPS = 8;
     // TOP: hittable.rs:45-58 from the slot's cursor; a mesh whose root box is hit sends the ray to WALK; at the end of the list the
     // slot is routed by the material class of its hit, so that SHADE passes are homogeneous.  Run by SHADE passes on the rays they
     // have just generated (still in registers) and by TOP1 passes on the slots whose walk is back.
@@ -498,6 +497,10 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 // Entry points: one body per material set (rt_device.h) -- and, for the set the mesh scenes use, per transform class of the meshes; the opt-in slab test only in the general form.
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MATS_ALL>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL>(P); }
+// ... and for lists whose meshes all have SMALL trees (every mesh <= WF_SHALLOW_NODES nodes: semesterbild's text mesh, 3 351 nodes, depth 11): WALK passes of 3 x 6 box tests instead of
+// 3 x 8 -- a shallow walk ends or stalls sooner, so the last steps of an 8-step round run nearly empty.  Round 5, 800x600x256 kernel ms (profiles/r05/ab_wavefront_walk_geometry_shallow.txt):
+// 3x8 26.68, 4x6 26.46, 3x6 26.36 (-1.2 %), 5x5 26.61, 4x5 26.63; teapot's deep trees (8 191 / 14 161 nodes) want 3 x 8 (every other geometry +1 ... +2.8 %, round 4).
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_shallow(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL, true, false, 8, 3, 6>(P); }
 // ... and for lists whose meshes are all untransformed (teapot -1.9 % at 256 spp, another -0.7 % with 12 inline steps; profiles/r04/ab_wavefront_transform_classes.txt)
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_ident(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL, true, true, 12>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF_MESHFREE) __attribute__((amdgpu_waves_per_eu(8, 8))) k_render_ctr_wf_meshfree(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_SPECULAR, false>(P); }

@@ -132,13 +132,13 @@ def test_mesh_kernels_equal_the_lockstep_walk(name, native, oracle_mod, abi, kno
     ctx.set_scene(sc, sc.camera, sc.settings)
     # neither scene has a metal: the wavefront kernel without that branch is the automatic choice -- for teapot, whose two meshes are untransformed,
     # in the instantiation that skips mesh_setup's matrix products (12); forcing 10 / 7 on it runs the general forms, which must agree bit for bit
-    assert ctx.kernel_variant() == (12 if name == "teapot" else 10)
+    assert ctx.kernel_variant() == (12 if name == "teapot" else 13)          # (13: the text mesh's tree is small -- 3 351 nodes -- so the instantiation with the shorter WALK rounds)
     ctx.close()
     if name == "semesterbild":                             # its mesh is rotated: the form for untransformed meshes must be refused, not run
         knobs(None, kernel=12)
-        ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings); assert ctx.kernel_variant() == 10; ctx.close()
+        ctx = device.Context(0); ctx.set_scene(sc, sc.camera, sc.settings); assert ctx.kernel_variant() == 13; ctx.close()
     outs = []
-    for library, kv in ((None, {"kernel": 1}), (None, {}), (None, {"kernel": 7}), (None, {"kernel": 10}),
+    for library, kv in ((None, {"kernel": 1}), (None, {}), (None, {"kernel": 7}), (None, {"kernel": 10}), (None, {"kernel": 13}),
                         (R, {"kernel": 1}), (R, {"kernel": 7}),
                         (R, {"kernel": 2, "trav_min": 1}), (R, {"kernel": 2, "trav_min": 64}), (R, {"kernel": 2}), (R, {"kernel": 2, "inline_steps": 0})):
         knobs(library, **kv)

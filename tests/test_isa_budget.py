@@ -16,6 +16,7 @@ BUDGET = {
     "k_render_ctr_nospec": (72, 7, 21 * 1024, 5),
     "k_render_ctr_nomesh": (80, 7, 23 * 1024, 6),
     "k_render_ctr_wf_nometal": (80, 8, 50 * 1024, 6),       # teapot, semesterbild: 6 waves per SIMD, 2 workgroups of 12 waves per CU
+    "k_render_ctr_wf_nometal_shallow": (80, 8, 46 * 1024, 6), # semesterbild: small trees, WALK rounds of 6 box tests
     "k_render_ctr_wf_nometal_ident": (80, 8, 52 * 1024, 6),   # teapot: the same for untransformed meshes
     "k_render_ctr_wf": (80, 12, 51 * 1024, 15),
     "k_render_ctr_wf_meshfree": (64, 18, 25 * 1024, 26),    # veach-mis: 8 waves per SIMD (round 5, pcg4d + REKEY: 17 spilled, measured -2.3 % against round 4)

@@ -34,7 +34,7 @@ for name, path, W, H, spp, depth, skip in [("cornell", "data/scenes/tungsten/cor
     blk = list(raw)[8:24]
     if sum(blk):
         rays = st.rays
-        wf = ctx.kernel_variant() in (7, 8, 10, 11)
+        wf = ctx.kernel_variant() in (7, 8, 10, 11, 12, 13)
         names = (["WALK passes", "TOP1 passes", "TOP passes that park walks (lanes = walks parked)", "SHADE+TOP0 passes", "WALK box-test steps (lanes stepping)",
                   "WALK leaf phases (lanes with a leaf)", "WALK passes (lanes = walks finished)", "inline box-test steps in TOP"] if wf
                  else ["inner-node steps", "leaf phases", "TOP passes", "SHADE passes"])
