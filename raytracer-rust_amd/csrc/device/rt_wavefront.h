@@ -496,13 +496,16 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #define MI355RT_OCC_WFK __attribute__((amdgpu_waves_per_eu(6, 6)))         // 80 VGPRs: 2 workgroups of 12 waves per CU (see the top of this file)
 // Entry points: one body per material set (rt_device.h) -- and, for the set the mesh scenes use, per transform class of the meshes; the opt-in slab test only in the general form.
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf(const RenderParams P) { render_ctr_wavefront<false, MATS_ALL>(P); }
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL>(P); }
+// WALK geometry by tree size (round 5; template arguments INLINE_STEPS, WF_ROUNDS, WF_STEPS): large trees want LONGER rounds -- teapot (8 191 / 14 161 nodes, depth 12 / 13), kernel ms at 800x600x256
+// (profiles/r05/ab_wavefront_walk_geometry_deep.txt): on its own instantiation 3 x 8 15.49, 3 x 9 15.31*, **3 x 10 15.33 (-1.0 %)**, 3 x 11 15.36, 3 x 12 15.59, 4 x 10 15.55, 2 x 12 15.33*; forced onto this general
+// form: 8 inline steps + 3 x 8 16.01, 8 + 3 x 10 15.81, **12 + 3 x 10 15.66 (-2.2 %)** (* = another session, base 15.40) -- small trees want SHORTER ones (k_render_ctr_wf_nometal_shallow below).
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL, true, false, 12, 3, 10>(P); }
 // ... and for lists whose meshes all have SMALL trees (every mesh <= WF_SHALLOW_NODES nodes: semesterbild's text mesh, 3 351 nodes, depth 11): WALK passes of 3 x 6 box tests instead of
 // 3 x 8 -- a shallow walk ends or stalls sooner, so the last steps of an 8-step round run nearly empty.  Round 5, 800x600x256 kernel ms (profiles/r05/ab_wavefront_walk_geometry_shallow.txt):
 // 3x8 26.68, 4x6 26.46, 3x6 26.36 (-1.2 %), 5x5 26.61, 4x5 26.63; teapot's deep trees (8 191 / 14 161 nodes) want 3 x 8 (every other geometry +1 ... +2.8 %, round 4).
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_shallow(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL, true, false, 8, 3, 6>(P); }
-// ... and for lists whose meshes are all untransformed (teapot -1.9 % at 256 spp, another -0.7 % with 12 inline steps; profiles/r04/ab_wavefront_transform_classes.txt)
-__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_ident(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL, true, true, 12>(P); }
+// ... and for lists whose meshes are all untransformed (teapot -1.9 % at 256 spp, another -0.7 % with 12 inline steps; profiles/r04/ab_wavefront_transform_classes.txt; round 5: rounds of 10 box tests, -1.0 %)
+__global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_nometal_ident(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_METAL, true, true, 12, 3, 10>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF_MESHFREE) __attribute__((amdgpu_waves_per_eu(8, 8))) k_render_ctr_wf_meshfree(const RenderParams P) { render_ctr_wavefront<false, MATS_NO_SPECULAR, false>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS_WF) MI355RT_OCC_WFK k_render_ctr_wf_fixaabb(const RenderParams P) { render_ctr_wavefront<true, MATS_ALL>(P); }
 
