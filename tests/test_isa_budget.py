@@ -37,3 +37,21 @@ def test_shipped_kernels_stay_inside_their_measured_budgets(native):
         assert st.get("scratch_insts", 0) <= scratch, (name, st)
     wf = stats["k_render_ctr_wf_nometal"]
     assert wf["group_segment_fixed_size"] <= 163840 // 2                            # two workgroups per CU share the 160 KB of LDS
+
+
+def test_isa_diff_tool_and_kernel_name_tables(native):
+    """tools/isa_stats.py --diff is the proof that a source clean-up changed nothing that runs: a library compared with itself is identical kernel by
+    kernel, and bench.py's table of kernel names (what the result line and the PMC file call the dominant kernel) names exactly the kernels the product
+    library holds plus the reference build's retired ones."""
+    isa_stats = importlib.import_module("isa_stats")
+    build = importlib.import_module("raytracer-rust_amd.build")
+    a = isa_stats.kernel_isa(build.DEVICE_SO)
+    assert len(a) >= 13 and all(len(v) > 100 for k, v in a.items() if "k_render" in k)
+    assert isa_stats.diff(build.DEVICE_SO, build.DEVICE_SO) == 0
+    assert isa_stats._commuted("v_add_f32_e32 v1, v2, v0") == isa_stats._commuted("v_add_f32_e32 v1, v0, v2") != isa_stats._commuted("v_sub_f32_e32 v1, v0, v2")
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    built = {isa_stats.short(k) for k in a if "k_render_ctr" in k}
+    named = set(bench.KERNEL_NAMES.values())
+    assert built <= named, built - named
+    assert named - built <= {"k_render_ctr_sm", "k_render_ctr_sm_fixaabb", "(retired)"}, named - built
