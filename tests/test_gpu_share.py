@@ -65,6 +65,11 @@ def test_bench_picks_streams_that_really_overlap(native):
     bench = importlib.import_module("bench")
     streams, info = bench.concurrent_streams(torch, torch.device("cuda", 0), 4)
     assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4
-    assert info["method"].startswith("torch.cuda._sleep") and info["queue_classes_found"] >= 4 and info["distinct"] == 4, info
+    # (4 classes on an MI355X with the runtime's default of 4 hardware queues -- seen in every session of round 5; the test insists on at least 2, so that a box whose
+    #  queues have other tenants does not turn a tuning aid into a red suite: bench.py itself falls back to the classes that exist, fit_frames_to_queues)
+    assert info["method"].startswith("torch.cuda._sleep") and info["queue_classes_found"] >= 2 and info["distinct"] == min(4, info["queue_classes_found"]), info
+    if info["queue_classes_found"] < 4:
+        import warnings
+        warnings.warn(f"stream probe found {info['queue_classes_found']} hardware-queue classes, not 4: {info}")
     again, _ = bench.concurrent_streams(torch, torch.device("cuda", 0), 2)          # cached per device: the same classes
     assert [s.cuda_stream for s in again] == [s.cuda_stream for s in streams[:2]]
