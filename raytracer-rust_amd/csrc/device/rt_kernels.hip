@@ -74,10 +74,8 @@ struct WorkCursorT {
     uint32_t shard = 0, dry = 0, seen = 0;      // current shard, consecutive dry shards, last counter value seen in it
     DI void init() { shard = xcc_id(); }
     DI bool exhausted() const { return no_more && next == end; }
-    // Lanes with want == true get a sample index (returns true and sets sidx); others / surplus stay idle.
-    DI bool deal(const RenderParams& P, bool want, uint32_t lane, uint32_t& sidx) {
-        const uint64_t idle = __ballot(want);
-        if (idle == 0ull) return false;
+    // One global atomic: the next run of the wave's shard (or of the next shard that still has work).  Wave-uniform.
+    DI void claim(const RenderParams& P, uint32_t lane) {
         while (next == end && !no_more) {
             const uint32_t base = shard * P.shard_samples;
             const uint32_t len = min(P.shard_samples, P.band_samples > base ? P.band_samples - base : 0u);
@@ -91,12 +89,50 @@ struct WorkCursorT {
                 if (++dry == WORK_SHARDS) no_more = true;
             } else { next = base + start; end = base + min(start + size, len); seen = start + size; dry = 0; }
         }
+    }
+    // Lanes with want == true get a sample index (returns true and sets sidx); others / surplus stay idle.
+    DI bool deal(const RenderParams& P, bool want, uint32_t lane, uint32_t& sidx) {
+        const uint64_t idle = __ballot(want);
+        if (idle == 0ull) return false;
+        claim(P, lane);
         const uint32_t take = min((uint32_t)__popcll(idle), end - next);
         bool got = false;
         if (take != 0u) {
             const uint32_t rank = mbcnt64(idle);
             if (want && rank < take) { sidx = next + rank; got = true; }
             next += take;
+        }
+        return got;
+    }
+    // The same, for a kernel that keeps camera rays IN STOCK (RayStock below): samples are dealt out of [next, stock_end), the part of the
+    // wave's run whose rays `refill(first, count)` has prepared -- up to 64 at a time, by the whole wave, whenever the stock runs out
+    // (also in the middle of a deal: the lanes the old stock could not serve are served from the new one in the same call).
+    uint32_t stock_end = 0;                                  // next == stock_end: the stock is empty
+    template <class Refill, class Take>
+    DI bool deal_stocked(const RenderParams& P, bool want, uint32_t lane, uint32_t& sidx, Refill&& refill, Take&& take_entry) {
+        uint64_t idle = __ballot(want);
+        if (idle == 0ull) return false;
+        uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle <= stock_end - next) {                    // the common case: the stock serves every idle lane
+            if (want) { sidx = next + mbcnt64(idle); take_entry(sidx); }
+            next += n_idle;
+            return want;
+        }
+        bool got = false;                                    // the stock runs out in this deal (once per 64 samples)
+        for (;;) {
+            if (next == stock_end) {
+                claim(P, lane);
+                if (next == end) break;                      // no work left anywhere
+                stock_end = next + min(64u, end - next);
+                refill(next, stock_end - next);
+            }
+            const uint32_t take = min(n_idle, stock_end - next);
+            const uint32_t rank = mbcnt64(idle);
+            if (want && !got && rank < take) { sidx = next + rank; got = true; take_entry(sidx); }   // (read before a refill reuses the entry)
+            next += take;
+            idle = __ballot(want && !got);
+            if (idle == 0ull) break;
+            n_idle = (uint32_t)__popcll(idle);
         }
         return got;
     }
@@ -123,6 +159,42 @@ struct PathState {
     uint32_t px, py;               // only meaningful while `fresh`
     RngCtr rng;
 };
+
+// Camera rays IN STOCK (lockstep kernels, round 5).  A path that ends hands its lane to a fresh sample in the same iteration, so every iteration
+// started a few paths -- 11 of 64 lanes on cornell, in 93 % of the iterations (profiles/r05/stamps_final_kernels.txt) -- and paid the whole
+// price of starting one for them: the sample index decoded, its row looked up (a global load the arithmetic half then waited for), the path's
+// generator base, the jitter block, u / v, Camera::get_ray: ~100 instructions at a sixth of the lanes.  Every one of those values is a pure function
+// of the sample index.  So the wave prepares the rays of the next (up to) 64 samples of its run AT ONCE, with all lanes, whenever its stock runs out
+// (WorkCursorT::deal_stocked), and keeps them in 2 KB of LDS: per sample the direction before its two normalisations (camera.rs:33-42; the shared
+// tail of the iteration normalises it with the scattered rays, as before) and the generator base.  A lane that is dealt sample i reads entry i mod 64:
+// two ds_read_b128.  Same arithmetic per path, same bits.  LDS operations of one wave execute in order: no barrier between refill and take.
+struct RayStock {
+    float4* dir; uint4* key;                                   // [64] each, this wave's
+    template <bool FASTN>
+    DI void refill(const RenderParams& P, uint32_t first, uint32_t count, uint32_t lane) const {
+        if (lane < count) {
+            const uint32_t sidx = first + lane;
+            RngCtr rng; uint32_t px, py;
+            start_path(P, sidx, rng, px, py);
+            rng.template load_block0<true>();                                                   // ray 0, block 0: the jitter (words 0 / 1)
+            const float un = (float)px + rng.jitter_u(), vn = (float)py + rng.jitter_v();
+            const float u = FASTN ? div_by_rn(un, P.width_f, P.inv_width_rn) : un / (float)P.width;       // renderer.rs:96
+            const float v = FASTN ? div_by_rn(vn, P.height_f, P.inv_height_rn) : vn / (float)P.height;    // renderer.rs:97
+            const f3 raw = camera_raw(P.cam, u, v);                                              // renderer.rs:99
+            dir[sidx & 63u] = make_float4(raw.x, raw.y, raw.z, 0.f);
+            if constexpr (RngCtr::NW == 4) key[sidx & 63u] = make_uint4(rng.w[0], rng.w[1], rng.w[2], rng.w[3]);
+        }
+    }
+    DI void take(const RenderParams& P, uint32_t sidx, f3& raw, PathState& ps) const {
+        const float4 d = dir[sidx & 63u];
+        raw = mk(d.x, d.y, d.z);
+        // (handing the key over only after the iteration's shared generator call -- a fresh path does not use that call's block -- so that the wave need not
+        //  wait for this read in front of it was measured: four more live registers, cornell +0.5 %, the general kernels +0.5 ... 2 %)
+        if constexpr (RngCtr::NW == 4) { const uint4 k = key[sidx & 63u]; ps.rng.w[0] = k.x; ps.rng.w[1] = k.y; ps.rng.w[2] = k.z; ps.rng.w[3] = k.w; }
+        else start_path(P, sidx, ps.rng, ps.px, ps.py);                                          // (the Philox builds address by (key, x, s): nothing to keep)
+    }
+};
+struct NoStock {};
 
 // random_in_unit_sphere (vec3.rs:54-61) for the whole wave at once, counter mode.  Try 0 comes from the event's
 // block 0 (already in rng.b0).  Lanes whose try 0 failed become OWNERS of a retry request; then every lane of
@@ -200,9 +272,11 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane, cons
 // REKEY (wavefront kernel: a path's generator state is not carried in its slot): the state is derived from the sample index HERE, once, for continuing
 // and freshly dealt lanes together, right in front of the event's block -- instead of by the caller when the slot is loaded (live through the hit record,
 // the material read and the radiance store) and a second time where fresh samples are dealt.
-template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, bool FASTN = false, int TRY1 = 0, bool REKEY = false, class WC>
+template <uint32_t MATS, bool DEFAULTS = true, bool WIDE = !DEFAULTS, bool DROP_PRIO = false, bool Q0_IN_HIT = false, bool FASTN = false, int TRY1 = 0, bool REKEY = false, class WC, class STOCK = NoStock>
 DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool& live, bool can_take, bool hit, const Hit& h,
-                             PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof) {
+                             PathState& ps, uint32_t& n_paths, uint32_t& n_rays, Prof& prof, const STOCK& stock = STOCK()) {
+    constexpr bool STOCKED = std::is_same<STOCK, RayStock>::value;                           // camera rays come out of the wave's stock (lockstep kernels)
+    static_assert(!STOCKED || (!DEFAULTS && !REKEY), "the stock serves the lockstep form");
     struct Rad { float x, y, z; };                                                        // 12 bytes per path: global_store_dwordx3
     Rad* __restrict__ radiance = reinterpret_cast<Rad*>(P.radiance);
     float4 q0;                                                                            // first 16 bytes of the hit material; read by lanes that loaded it
@@ -221,6 +295,11 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
     }
     prof.mark(2);
     bool fresh = false;
+    f3 stocked_raw = mk(0.f, 0.f, 1.f);
+    if constexpr (STOCKED) {
+        if (wc.deal_stocked(P, can_take && !live, lane, ps.sidx, [&](uint32_t first, uint32_t count) { stock.template refill<FASTN>(P, first, count, lane); },
+                            [&](uint32_t sidx) { stock.take(P, sidx, stocked_raw, ps); })) { fresh = true; live = true; ++n_paths; }
+    } else
     if (wc.deal(P, can_take && !live, lane, ps.sidx)) { if constexpr (!REKEY) start_path(P, ps.sidx, ps.rng, ps.px, ps.py); fresh = true; live = true; ++n_paths; }
     if constexpr (DROP_PRIO) __builtin_amdgcn_s_setprio(0);                               // the lockstep kernels' arithmetic half (see render_ctr_lockstep)
     if (__ballot(live) == 0ull) return !wc.exhausted();
@@ -273,15 +352,18 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
             if (fresh) {
                 // (FASTN: div_bounded with the host's RN(1/width) -- the dividend is 0 or in [2^-24, 2^24), the divisor an image dimension in [1, 2^24);
                 //  with the reciprocal computed in the kernel the compiler hoisted it into four vector registers that the loop then spilled)
+                if constexpr (STOCKED) raw = stocked_raw;                                    // RayStock::refill computed it, with all lanes at once
+                else {
                 const float un = (float)ps.px + ps.rng.jitter_u(), vn = (float)ps.py + ps.rng.jitter_v();
                 const float u = FASTN ? div_by_rn(un, P.width_f, P.inv_width_rn) : un / (float)P.width;       // renderer.rs:96
                 const float v = FASTN ? div_by_rn(vn, P.height_f, P.inv_height_rn) : vn / (float)P.height;    // renderer.rs:97
                 raw = camera_raw(P.cam, u, v);                                               // renderer.rs:99; normalised below with the scattered rays
+                }
                 n_ro = mk(P.cam.position[0], P.cam.position[1], P.cam.position[2]);
                 n_thr = mk(1.f, 1.f, 1.f); n_ri = 0;
                 if (P.max_depth == 0u) { radiance[ps.sidx] = Rad{0.f, 0.f, 0.f}; live = false; }   // depth == 0 -> BLACK
             } else {
-                scattered = scatter_pre<MATS, WIDE, FASTN>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
+                scattered = scatter_pre<MATS, WIDE, FASTN, /* TERMINAL_DONE */ true>(P.mats, P.textures, q0, h, ps.rd, ps.rng, side, raw, atten, emitted, ball_use, fuzz);
             }
         }
         prof.mark(5);
@@ -333,6 +415,13 @@ DI void render_ctr_lockstep(const RenderParams& P) {
     cprim_t prims = (cprim_t)(P.prims);
     const uint32_t lane = threadIdx.x & 63u;
     WorkCursor wc; wc.init();
+#ifdef MI355RT_AB_NOSTOCK
+    NoStock stock;
+#else
+    __shared__ __attribute__((aligned(16))) float4 s_stock_dir[BLOCK_THREADS];                // RayStock: 64 entries per wave
+    __shared__ __attribute__((aligned(16))) uint4 s_stock_key[BLOCK_THREADS];
+    RayStock stock; stock.dir = s_stock_dir + (threadIdx.x & ~63u); stock.key = s_stock_key + (threadIdx.x & ~63u);
+#endif
     PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
     ps.rng.clear();
     bool live = false;
@@ -352,7 +441,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         __builtin_amdgcn_s_setprio(1);
         if (live) hit = hit_scene<HAS_MESH, true>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
-        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, /* FASTN */ true, /* TRY1 */ SIMPLE ? 1 : 0>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof)) break;
+        if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, /* FASTN */ true, /* TRY1 */ SIMPLE ? 1 : 0>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof, stock)) break;
         prof.mark(4);
 #ifdef MI355RT_STAMPS
         if (wc.exhausted()) {                              // all work dealt: from here on the wave only drains its own paths

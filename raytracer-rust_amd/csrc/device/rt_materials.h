@@ -75,7 +75,9 @@ DI f3 texture_lookup(const DevTexture* __restrict__ texs, uint32_t index, float 
 }
 
 enum : uint32_t { BALL_NONE = 0, BALL_DIFFUSE = 1, BALL_METAL = 2 };    // what a scatter event needs a random_in_unit_sphere point for
-template <uint32_t MATS, bool WIDE = false, bool FASTN = false, class Rng>
+// TERMINAL_DONE: the caller has already finished the paths that hit an emitter or a null material (shade_and_regenerate classifies them before it deals
+// fresh samples), so no lane arrives here with one: the two tests below -- and the mask bookkeeping the compiler builds around them -- are compiled out.
+template <uint32_t MATS, bool WIDE = false, bool FASTN = false, bool TERMINAL_DONE = false, class Rng>
 DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restrict__ texs, const float4 q0, const Hit& h, f3 rd_in, Rng& rng, float& side, f3& raw_d, f3& atten, f3& emitted, uint32_t& ball_use, float& fuzz_out) {
     const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mats + (h.mat_ff & 0x7FFFFFFFu));
     const uint32_t kind = __float_as_uint(q0.x);
@@ -84,8 +86,10 @@ DI bool scatter_pre(const DevMat* __restrict__ mats, const DevTexture* __restric
     emitted = mk(0.f, 0.f, 0.f);
     ball_use = BALL_NONE;
     side = EPS;                                                                    // every material but the dielectric leaves on the normal's side
+    if constexpr (!TERMINAL_DONE) {
     if (kind == MI355RT_MAT_EMISSIVE) { emitted = albedo; return false; }         // material.rs:179-191
     if (kind == MI355RT_MAT_NULL) return false;                                   // material.rs:239-251
+    }
     rng.begin_scatter();
     bool diffuse = false;                                                          // Lambert-style bounce shared by 3 materials
     atten = albedo;
