@@ -427,18 +427,29 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         }
         if (p.kind == MI355RT_PRIM_CUBE || p.kind == MI355RT_PRIM_MESH) {
             const float* o2w = p.data; const float* w2o = p.data + 16;
-            std::memcpy(d.d, w2o, 64);
-            for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) d.d[16 + 3 * c + r] = o2w[4 * c + r];
+            float t[52] = {};                                 // matrix-shaped staging: w2o[16] column-major, o2w[12], zd[3], zn[3], the cube's normal table
+            std::memcpy(t, w2o, 64);
+            for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) t[16 + 3 * c + r] = o2w[4 * c + r];
             volatile float zero = 0.0f;                       // keep the IEEE product (sign of zero, NaN) exactly
-            for (int r = 0; r < 3; ++r) d.d[28 + r] = w2o[12 + r] * zero;
-            for (int r = 0; r < 3; ++r) d.d[31 + r] = w2o[4 * r + 3] * zero;
-            if (p.kind == MI355RT_PRIM_CUBE) cube_normal_table(d.d);
+            for (int r = 0; r < 3; ++r) t[28 + r] = w2o[12 + r] * zero;
+            for (int r = 0; r < 3; ++r) t[31 + r] = w2o[4 * r + 3] * zero;
+            if (p.kind == MI355RT_PRIM_CUBE) cube_normal_table(t);
+            // The record (rt_device.h): what the hit test reads -- the 3 x 3 part of w2o, its translation, zd -- as ONE run of 15 words, so that the
+            // wave-uniform walk fetches it with one scalar load instead of ten pieces picked out of a 4 x 4 matrix.
+            for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) d.d[3 * c + r] = t[4 * c + r];
+            for (int r = 0; r < 3; ++r) d.d[12 + r] = t[28 + r];
+            for (int k = 16; k < 28; ++k) d.d[k] = t[k];
+            for (int k = 31; k < 52; ++k) d.d[k] = t[k];
             if (p.kind == MI355RT_PRIM_MESH) {
                 if (p.mesh >= sc->n_meshes) return fail(MI355RT_ERR_INVALID, "primitive mesh index");
                 d.node_begin = mesh_roots[p.mesh];
                 all_meshes_identity = all_meshes_identity && xform_is_identity(w2o);
                 all_meshes_shallow = all_meshes_shallow && sc->meshes[p.mesh].node_count <= WF_SHALLOW_NODES;
             }
+        } else if (p.kind == MI355RT_PRIM_QUAD) {               // normal and plane constant first (what every ray needs), then base, e0, e1, the two 1 / |e|^2
+            for (int k = 0; k < 4; ++k) d.d[k] = p.data[9 + k];
+            for (int k = 0; k < 9; ++k) d.d[4 + k] = p.data[k];
+            d.d[13] = p.data[13]; d.d[14] = p.data[14];
         } else {
             std::memcpy(d.d, p.data, 32 * sizeof(float));
         }

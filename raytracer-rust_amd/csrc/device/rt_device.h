@@ -28,9 +28,9 @@ namespace mi355rt {
 struct DevPrim {                 // 60 words = 240 B
     uint32_t kind, material, node_begin, run_end;    // node_begin: root node of a MI355RT_PRIM_MESH; run_end: list index one past the
                                                      // run of consecutive primitives of this kind that this one belongs to (> own index)
-    // sphere: c[3], r | plane: p1[3], n[3] | quad: base, e0, e1, n, d, inv0, inv1 (15)
-    // cube / mesh: w2o[16] (column-major), o2w rows 0..2 of its 4 columns as o2w[12] = {c0.xyz, c1.xyz, c2.xyz, c3.xyz},
-    //              zd[3] = w2o.w_axis.xyz * 0.0f, zn[3] = {w2o[3], w2o[7], w2o[11]} * 0.0f,
+    // sphere: c[3], r | plane: p1[3], n[3] | quad: n[3], d, base[3], e0[3], e1[3], inv0, inv1 (15; normal and plane constant first: every ray needs them)
+    // cube / mesh: d[0..11] = rows 0..2 of the 4 columns of w2o {c0.xyz, c1.xyz, c2.xyz, c3.xyz}, d[12..14] = zd[3] = w2o.w_axis.xyz * 0.0f -- the 15 words
+    //              of the hit test in one run (one scalar load) --, d[16..27] = o2w likewise, d[31..33] = zn[3] = {w2o[3], w2o[7], w2o[11]} * 0.0f,
     //              cube only: d[34..51] = the 6 possible world normals normalized(w2o^T * (+-e_k, 0)), k = x,y,z, + then -
     float d[52];
     float mat0[4];                                   // a copy of the first 16 bytes of the primitive's material record (kind, albedo):

@@ -44,6 +44,7 @@ DI void set_face(Hit& h, f3 rd, f3 outward, uint32_t material) {                
 // place that changes the loop-carried candidate is cand_take()'s selects.  (A test that assigned the candidate inside its own
 // branches made the compiler carry two copies of it through the structurised switch: ~10 v_mov per quad, ~25 per cube.)
 struct Probe { float t, aux; f3 po; };
+typedef float rec16_t __attribute__((ext_vector_type(16)));
 DI bool cand_take(Cand& c, bool acc, uint32_t i, float t) { c.t = acc ? t : c.t; c.idx = acc ? i : c.idx; return acc; }
 DI bool cand_take(Cand& c, bool acc, uint32_t i, const Probe& o) { c.aux = acc ? o.aux : c.aux; return cand_take(c, acc, i, o.t); }
 DI bool cand_take(CandP& c, bool acc, uint32_t i, const Probe& o) {
@@ -85,35 +86,39 @@ DI bool hit_plane(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
 // compiler's division (ballot); infinities and NaN come out of v_div_fixup_f32 as they do there.
 template <bool FASTD = false>
 DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
-    f3 n = mk(pr->d[9], pr->d[10], pr->d[11]);
+    const rec16_t q = *reinterpret_cast<const __attribute__((address_space(4))) rec16_t*>(pr->d);     // the whole record: ONE scalar load
+    f3 n = mk(q[0], q[1], q[2]);
     float denom = dot(n, rd);
-    const float num = pr->d[12] - dot(n, ro);
+    const float num = q[3] - dot(n, ro);
     float t;
-    if (FASTD && __ballot(fabsf(num) >= 0x1p100f) == 0ull) t = div_bounded(num, denom); else
+    if (FASTD && __builtin_expect(__ballot(fabsf(num) >= 0x1p100f) == 0ull, 1)) t = div_bounded(num, denom); else
     t = num / denom;
-    const bool candidate = !(fabsf(denom) < EPS) && !(t <= t_min || t >= c.t);
-    // branch-free in the source: cornell 19.74 -> 19.61 ms, veach-mis +-0 with the 4-register candidate (the compiler still branches
-    // around the parallelogram test where a whole wave can skip it)
-    // every lane runs the parallelogram test; the candidate is updated by two selects (no exec-mask region, no copies per level)
+    // Branch-free, and since round 5 also in the ISA: the predicate is built with `&` / `|` on the comparison results, not `&&` / `||`.  With the
+    // short-circuit operators the compiler fenced the parallelogram test with two exec-mask regions (s_and_saveexec, s_cbranch_execz, s_or exec,
+    // mask merges: ~12 scalar instructions per quad) that a wave of incoherent rays never skips, and read the record in four pieces with a wait in
+    // front of each region.  The kernels' time follows the TOTAL instruction count, scalar ones included (profiles/r05/ab_lockstep_ray_stock.txt),
+    // so: one s_load_dwordx16 for the record (its layout puts what every ray needs first, rt_device.h), one wait, straight-line arithmetic,
+    // two selects on the candidate.  cornell 13.03 -> 12.61 ms of kernel (profiles/r05/ab_scalar_diet.txt).
+    const bool candidate = !(fabsf(denom) < EPS) & !((t <= t_min) | (t >= c.t));
     f3 hit_pos = ro + rd * t;
-    f3 v = hit_pos - mk(pr->d[0], pr->d[1], pr->d[2]);
-    float l0 = dot(v, mk(pr->d[3], pr->d[4], pr->d[5])) * pr->d[13];
-    float l1 = dot(v, mk(pr->d[6], pr->d[7], pr->d[8])) * pr->d[14];
+    f3 v = hit_pos - mk(q[4], q[5], q[6]);
+    float l0 = dot(v, mk(q[7], q[8], q[9])) * q[13];
+    float l1 = dot(v, mk(q[10], q[11], q[12])) * q[14];
     const float lo = -EPS, hi = 1.0f + EPS;
-    return cand_take(c, candidate && ((l0 >= lo && l0 <= hi) && (l1 >= lo && l1 <= hi)), i, t);
+    return cand_take(c, candidate & (((l0 >= lo) & (l0 <= hi)) & ((l1 >= lo) & (l1 <= hi))), i, t);
 }
 
 // glam Mat4 * Vec4 pieces on the DevPrim cube/mesh record (see rt_device.h for the layout).  PrimPtr is the wave-uniform
 // constant-address-space pointer of the list walk (scalar loads) or a per-lane global pointer in finish_hit().
 template <class PrimPtr> DI f3 xform_w2o_point(PrimPtr pr, f3 p) {            // (w2o * (p, 1)).xyz
     const auto* m = pr->d;
-    return mk(((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12], ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13],
-              ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14]);
+    return mk(((m[0] * p.x + m[3] * p.y) + m[6] * p.z) + m[9], ((m[1] * p.x + m[4] * p.y) + m[7] * p.z) + m[10],
+              ((m[2] * p.x + m[5] * p.y) + m[8] * p.z) + m[11]);
 }
 template <class PrimPtr> DI f3 xform_w2o_dir(PrimPtr pr, f3 v) {              // (w2o * (v, 0)).xyz ; zd = w_axis * 0.0f keeps -0.0 behaviour
     const auto* m = pr->d;
-    return mk(((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[28], ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[29],
-              ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[30]);
+    return mk(((m[0] * v.x + m[3] * v.y) + m[6] * v.z) + m[12], ((m[1] * v.x + m[4] * v.y) + m[7] * v.z) + m[13],
+              ((m[2] * v.x + m[5] * v.y) + m[8] * v.z) + m[14]);
 }
 template <class PrimPtr> DI f3 xform_o2w_point(PrimPtr pr, f3 p) {            // (o2w * (p, 1)).xyz
     const auto* m = pr->d + 16;
@@ -122,8 +127,8 @@ template <class PrimPtr> DI f3 xform_o2w_point(PrimPtr pr, f3 p) {            //
 }
 template <class PrimPtr> DI f3 xform_normal(PrimPtr pr, f3 n) {               // (w2o.transpose() * (n, 0)).xyz
     const auto* m = pr->d;
-    return mk(((m[0] * n.x + m[1] * n.y) + m[2] * n.z) + m[31], ((m[4] * n.x + m[5] * n.y) + m[6] * n.z) + m[32],
-              ((m[8] * n.x + m[9] * n.y) + m[10] * n.z) + m[33]);
+    return mk(((m[0] * n.x + m[1] * n.y) + m[2] * n.z) + m[31], ((m[3] * n.x + m[4] * n.y) + m[5] * n.z) + m[32],
+              ((m[6] * n.x + m[7] * n.y) + m[8] * n.z) + m[33]);
 }
 DI float glam_signum(float v) { if (v != v) return v; return copysignf(1.0f, v); }
 
@@ -148,8 +153,11 @@ DI uint32_t cube_axis(f3 po) {                                                  
 }
 template <bool FASTR = false, class C>
 DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, C& c) {
-    f3 ro = xform_w2o_point(pr, ro_w);
-    f3 rd = xform_w2o_dir(pr, rd_w);
+    const rec16_t m = *reinterpret_cast<const __attribute__((address_space(4))) rec16_t*>(pr->d);     // w2o (3 x 4) and zd: ONE scalar load
+    f3 ro = mk(((m[0] * ro_w.x + m[3] * ro_w.y) + m[6] * ro_w.z) + m[9], ((m[1] * ro_w.x + m[4] * ro_w.y) + m[7] * ro_w.z) + m[10],
+               ((m[2] * ro_w.x + m[5] * ro_w.y) + m[8] * ro_w.z) + m[11]);                             // xform_w2o_point
+    f3 rd = mk(((m[0] * rd_w.x + m[3] * rd_w.y) + m[6] * rd_w.z) + m[12], ((m[1] * rd_w.x + m[4] * rd_w.y) + m[7] * rd_w.z) + m[13],
+               ((m[2] * rd_w.x + m[5] * rd_w.y) + m[8] * rd_w.z) + m[14]);                             // xform_w2o_dir
     float ix, iy, iz; recip3<FASTR>(rd.x, rd.y, rd.z, ix, iy, iz);                  // (FASTR: the kernels of mesh-free lists, like normalized<FASTN>)
     float t1x = (-0.5f - ro.x) * ix, t2x = (0.5f - ro.x) * ix;
     float t1y = (-0.5f - ro.y) * iy, t2y = (0.5f - ro.y) * iy;
@@ -158,7 +166,7 @@ DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, C& c) {
     float t_exit = fminf(fmaxf(t1x, t2x), fminf(fmaxf(t1y, t2y), fmaxf(t1z, t2z)));
     const float t_hit = (t_enter > 0.0f) ? t_enter : t_exit;
     const float t_max = c.t;
-    const bool candidate = !(t_exit < t_enter || t_exit <= 0.0f) && !(t_hit >= t_max || t_hit <= t_min || t_hit < EPS);   // cube.rs:90-103, one branch
+    const bool candidate = !((t_exit < t_enter) | (t_exit <= 0.0f)) & !((t_hit >= t_max) | (t_hit <= t_min) | (t_hit < EPS));   // cube.rs:90-103, one branch (`|` / `&`: one exec-mask region, not three)
     Probe o; o.t = 0.f; o.aux = t_hit;
     bool acc = false;
     if (candidate) {
@@ -166,7 +174,7 @@ DI bool hit_cube(cprim_t pr, uint32_t i, f3 ro_w, f3 rd_w, float t_min, C& c) {
         o.po = po;
         f3 pw = xform_o2w_point(pr, po);
         o.t = dot(pw - ro_w, rd_w);                                                         // cube.rs:145-153: the same dot product twice
-        acc = !((o.t < 0.0f) || (o.t < t_min || o.t > t_max));
+        acc = !((o.t < 0.0f) | (o.t < t_min) | (o.t > t_max));
     }
     return cand_take(c, acc, i, o);
 }
@@ -350,7 +358,7 @@ DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__
     if (shared_tail) {
         f3 p = ro + rd * c.t, outward;                                        // sphere.rs:35, plane.rs:40, quad.rs:103
         if (kind == MI355RT_PRIM_QUAD) {                                      // quad.rs:103-131
-            outward = mk(pr->d[9], pr->d[10], pr->d[11]);                     // dot(ray.direction, normal): the same sum of the same products as `denom`
+            outward = mk(pr->d[0], pr->d[1], pr->d[2]);                     // dot(ray.direction, normal): the same sum of the same products as `denom`
         } else if (kind == MI355RT_PRIM_CUBE) {
             finish_cube(pr, c, ro, rd, p, outward);
         } else if (kind == MI355RT_PRIM_SPHERE) {                             // sphere.rs:35-52
@@ -366,7 +374,7 @@ DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__
         h.t = c.t;
         if (kind == MI355RT_PRIM_QUAD) {
             h.p = ro + rd * c.t;
-            set_face(h, rd, mk(pr->d[9], pr->d[10], pr->d[11]), pr->material);
+            set_face(h, rd, mk(pr->d[0], pr->d[1], pr->d[2]), pr->material);
         } else if (kind == MI355RT_PRIM_CUBE) {
             f3 outward; finish_cube(pr, c, ro, rd, h.p, outward);
             set_face(h, rd, outward, pr->material);
@@ -393,6 +401,8 @@ DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
     // candidate through a chain of merge blocks with register copies at every one of them.
     // The kinds are tried in a fixed cyclic order, each as `if (the run at i is of this kind) loop over the run`: plain nested
     // structured control flow (a `switch` here is lowered to a chain of flow blocks, each with its own copies of the candidate).
+    // (Round 5 measured the tidier form again -- ONE read of the run's header, kind and run_end together, and a wave-uniform `else if` chain over the
+    // kinds: cornell +2.8 %, profiles/r05/ab_scalar_diet.txt.)
     uint32_t i = 0;
     while (i < n_prims) {
 #define MI_RUN(KIND, CALL) if (i < n_prims && prims[i].kind == (KIND)) { const uint32_t end = min(prims[i].run_end, n_prims); do { CALL; } while (++i < end); }

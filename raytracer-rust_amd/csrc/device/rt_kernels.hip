@@ -415,13 +415,9 @@ DI void render_ctr_lockstep(const RenderParams& P) {
     cprim_t prims = (cprim_t)(P.prims);
     const uint32_t lane = threadIdx.x & 63u;
     WorkCursor wc; wc.init();
-#ifdef MI355RT_AB_NOSTOCK
-    NoStock stock;
-#else
     __shared__ __attribute__((aligned(16))) float4 s_stock_dir[BLOCK_THREADS];                // RayStock: 64 entries per wave
     __shared__ __attribute__((aligned(16))) uint4 s_stock_key[BLOCK_THREADS];
     RayStock stock; stock.dir = s_stock_dir + (threadIdx.x & ~63u); stock.key = s_stock_key + (threadIdx.x & ~63u);
-#endif
     PathState ps; ps.ro = mk(0, 0, 0); ps.rd = mk(0, 0, 1); ps.thr = mk(1, 1, 1); ps.sidx = 0; ps.ray_index = 0; ps.px = ps.py = 0;
     ps.rng.clear();
     bool live = false;
