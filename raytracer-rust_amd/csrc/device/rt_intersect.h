@@ -105,7 +105,11 @@ DI bool hit_quad(cprim_t pr, uint32_t i, f3 ro, f3 rd, float t_min, Cand& c) {
     float l0 = dot(v, mk(q[7], q[8], q[9])) * q[13];
     float l1 = dot(v, mk(q[10], q[11], q[12])) * q[14];
     const float lo = -EPS, hi = 1.0f + EPS;
-    return cand_take(c, candidate & (((l0 >= lo) & (l0 <= hi)) & ((l1 >= lo) & (l1 <= hi))), i, t);
+    // lo <= l <= hi as ONE comparison: the median of (l, lo, hi) is l exactly when l lies between them; for a NaN l v_med3_f32 returns the minimum of the
+    // other two, which no NaN equals -- false, like the two comparisons it replaces (-0.25 %).
+    // (Measured and not kept, profiles/r05/ab_scalar_diet.txt: ONE test of the ray's origin per walk against a host-derived bound instead of the 2^100 test of
+    // every quad's numerator, with a copy of the run loop without it: +1.5 % -- at this point the loop's layout weighs more than six instructions.)
+    return cand_take(c, candidate & ((__builtin_amdgcn_fmed3f(l0, lo, hi) == l0) & (__builtin_amdgcn_fmed3f(l1, lo, hi) == l1)), i, t);
 }
 
 // glam Mat4 * Vec4 pieces on the DevPrim cube/mesh record (see rt_device.h for the layout).  PrimPtr is the wave-uniform
