@@ -753,6 +753,10 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
         variant = ctx->variant == KERNEL_STATE_MACHINE ? (uint32_t)KERNEL_STATE_MACHINE_FIXAABB : (uint32_t)KERNEL_WAVEFRONT_FIXAABB;
         if (!render_ctr_variant_built(variant)) variant = KERNEL_WAVEFRONT_FIXAABB;
     }
+    // The mesh-free lockstep kernels are compiled under the assumption that the list holds something and that a path may take a step (rt_kernels.hip,
+    // render_ctr_lockstep); the two degenerate renders -- every sample is the miss colour / BLACK -- go to the plain per-lane loop, which assumes nothing.
+    if ((ctx->n_prims == 0 || st.max_depth == 0) && (variant == KERNEL_LOCKSTEP || variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_LOCKSTEP_NOSPEC))
+        variant = KERNEL_LOCKSTEP_MESH;
     const uint64_t seed = opt ? opt->seed : 0;
     const uint32_t n_rows = (uint32_t)ctx->rows_host.size();
     if (stats) { std::memset(stats, 0, sizeof *stats); stats->rows_rendered = n_rows; stats->kernel_vgprs = (uint32_t)ctx->vgprs[variant]; stats->kernel_sgprs = (uint32_t)ctx->sgprs; }

@@ -120,3 +120,29 @@ def test_a_scaled_quad_normal_is_refused(native, oracle_mod, abi):
         assert rc == abi.ERR_INVALID and "quad normal" in msg, (bad, rc, msg)
     quad.data[10] = old
     assert _render_rc(device, abi, sc, sc.camera, sc.settings)[0] == 0
+
+
+@pytest.mark.gpu
+def test_degenerate_renders_go_to_the_plain_loop(native, oracle_mod, abi):
+    """The mesh-free lockstep kernels are compiled for lists that hold something and for paths that may take a step (rt_kernels.hip render_ctr_lockstep:
+    __builtin_assume); rt_api.cpp sends the two degenerate renders -- an empty list, max_depth == 0 -- to the plain per-lane loop.  Every sample is the
+    miss colour / BLACK, with the oracle's ray counts, whichever kernel the scene would otherwise pick."""
+    from fuzz_scenes import random_scene
+    host, device = native
+    empty = random_scene(abi, host, 7, True, n_prims=0, only_kinds=[abi.PRIM_QUAD])
+    st = abi.Settings(24, 18, 5, 6)
+    for mode in (0, 1):
+        opt = abi.Options.make(rng_mode=mode, seed=11 if mode == 0 else 0)
+        gp, gl, gs = device.render(empty, empty.camera, st, opt)
+        op, ol, cnt = oracle_mod.render(empty, empty.camera, st, opt)
+        assert np.array_equal(gp, op) and np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and gs.rays == cnt.rays == 24 * 18 * 5
+    for kw in (dict(n_prims=9, only_kinds=[2, 3], lambert_only=True), dict(n_prims=9, only_kinds=[2, 3, 0, 1])):   # k_render_ctr_simple; the general mesh-free kernels
+        sc = random_scene(abi, host, 8, True, **kw)
+        st0 = abi.Settings(24, 18, 5, 0)
+        gp, gl, gs = device.render(sc, sc.camera, st0, abi.Options.make())
+        op, ol, cnt = oracle_mod.render(sc, sc.camera, st0, abi.Options.make())
+        assert np.all(gp == 0) and np.array_equal(gp, op) and gs.rays == cnt.rays == 0 and gs.samples == 24 * 18 * 5
+        st1 = abi.Settings(24, 18, 5, 1)                                                                          # ... and one step: the assuming kernels
+        gp, gl, gs = device.render(sc, sc.camera, st1, abi.Options.make())
+        op, ol, cnt = oracle_mod.render(sc, sc.camera, st1, abi.Options.make())
+        assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and gs.rays == cnt.rays
