@@ -24,8 +24,11 @@ CLI = os.path.join(OUT, "rt_render")
 # CPU oracle is bit-level.  Correctly rounded f32 divide/sqrt are HIP's default; stated explicitly.
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent f32 ops into v_pk_mul/add_f32, which issue slower than
 # the two scalar ops they replace on gfx950 (measured: -6 % kernel time on cornell, identical results).
+# -amdgpu-atomic-optimizer-strategy=None: the kernels' atomics (the work cursor, the wavefront kernels' queue tickets) are issued by ONE lane already; the
+# optimizer pass wraps each of them in a second single-lane election (mbcnt, bcnt, a multiply, readfirstlane: ~10 instructions per atomic) that can never
+# merge anything.  Round 5: mesh scenes and veach-mis -0.6 ... -0.8 %, cornell +-0 (profiles/r05/ab_scalar_diet.txt).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall",
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-command-line-argument"]
 CXX_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-pthread"]
 

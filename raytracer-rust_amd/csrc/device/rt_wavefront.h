@@ -115,6 +115,10 @@ struct SlotIO {
     }
 };
 
+// Ring entries are polled, hence volatile -- and the compiler's address-space inference leaves volatile accesses alone: through a plain pointer they were
+// FLAT loads / stores (nine of each in the kernel), every one followed by s_waitcnt vmcnt(0) lgkmcnt(0), i.e. a wait for ALL of the wave's outstanding
+// global memory traffic in every pop and every push.  The pointer says where the rings are: ds_read_u16 / ds_write_b16, counted in lgkmcnt alone.
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
 struct WfQueues {
     uint32_t* ctrl;        // [q] head, [8 + q] tail, [16] live paths, [17] error
     uint16_t* rings;       // WF_QUEUES x WF_RING slot numbers
@@ -135,7 +139,7 @@ struct WfQueues {
         }
         h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h); n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
         if (lane >= lane0 && lane < lane0 + n) {
-            volatile uint16_t* e = rings + q * WF_RING + ((h + lane - lane0) & (WF_RING - 1u));
+            volatile lds_u16_t* e = (volatile lds_u16_t*)(rings + q * WF_RING + ((h + lane - lane0) & (WF_RING - 1u)));
             uint32_t v = WF_EMPTY, spins = 0;
             for (;;) {                                                   // the pusher reserved this ticket and is about to write it
                 v = *e;
@@ -157,7 +161,7 @@ struct WfQueues {
         if (lane == first) base = atomicAdd(&ctrl[8u + q], (uint32_t)__popcll(m));
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
         if (pred) {
-            volatile uint16_t* e = rings + q * WF_RING + ((base + mbcnt64(m)) & (WF_RING - 1u));
+            volatile lds_u16_t* e = (volatile lds_u16_t*)(rings + q * WF_RING + ((base + mbcnt64(m)) & (WF_RING - 1u)));
             // The entry of ticket T is free once the popper of ticket T - WF_RING has read it and written EMPTY back.  That popper
             // exists (a ring holds more entries than there are slots, so ticket T - WF_RING was popped before T could be reserved);
             // if it has been held up between reserving and reading, wait for it instead of overwriting its entry.
