@@ -170,14 +170,32 @@ struct WfQueues {
             *e = (uint16_t)id;
         }
     }
-    // Every lane with `pred` pushes its slot to ITS queue `q` (lanes may name different queues): one reservation per queue present.
-    DI void push_each(bool pred, uint32_t q, uint32_t id, uint32_t lane, bool& failed) const {
-        uint64_t rem = __ballot(pred);
-        while (rem != 0ull) {
-            const uint32_t qq = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)__builtin_ctzll(rem));
-            const bool mine = pred && q == qq;
-            push(qq, mine, id, lane, failed);
-            rem &= ~__ballot(mine);
+    // Every lane with `pred` pushes its slot to ITS queue `q` (lanes may name different queues), in ONE reservation: the pass's slots go to at most NQ queues (WALK and
+    // the four SHADE classes), so lane j counts the slots bound for the j-th of them and a single ds_add_rtn_u32 -- per-lane address, per-lane count -- draws the tickets
+    // of all queues at once: one LDS round trip instead of one per queue present (a loop over the queues present, typically three, until round 5: veach-mis -1.0 %,
+    // the mesh scenes +-0; profiles/r05/ab_scalar_diet.txt).  Ticket order between queues is free (a path's arithmetic does not depend on which pass it rides in).
+    template <bool MESH>
+    DI void push_all(bool pred, uint32_t q, uint32_t id, uint32_t lane, bool& failed) const {
+        if (__ballot(pred) == 0ull) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the slot's stores are visible before its number is
+        constexpr int NQ = MESH ? 5 : 4;
+        auto queue_at = [](uint32_t j) { return MESH ? (j == 0u ? (uint32_t)WQ_WALK : (uint32_t)WQ_SHADE + j - 1u) : (uint32_t)WQ_SHADE + j; };
+        uint64_t m[NQ]; uint32_t bound = 0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) { m[j] = __ballot(pred && q == queue_at((uint32_t)j)); bound = (lane == (uint32_t)j) ? (uint32_t)__popcll(m[j]) : bound; }
+        uint32_t base = 0;
+        if (lane < (uint32_t)NQ) base = atomicAdd(&ctrl[8u + queue_at(lane)], bound);    // (a count of zero leaves that tail where it is)
+        uint32_t ticket = 0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)base, j);
+            ticket = (q == queue_at((uint32_t)j)) ? bj + mbcnt64(m[j]) : ticket;
+        }
+        if (pred) {
+            volatile lds_u16_t* e = (volatile lds_u16_t*)(rings + q * WF_RING + (ticket & (WF_RING - 1u)));
+            uint32_t spins = 0;
+            while (*e != WF_EMPTY) { if (++spins > entry_spins) { failed = true; break; } }      // (see push(): the popper of the previous revolution)
+            *e = (uint16_t)id;
         }
     }
     DI uint32_t count(uint32_t q) const {
@@ -292,7 +310,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
         if (have && !to_walk && c.idx != CAND_NONE) cls = shade_class(prim_material_kind(P, c.idx));
         MI355RT_WFCOUNT(2, (uint32_t)__popcll(__ballot(have && to_walk)));
         __builtin_amdgcn_s_setprio(WF_PRIO_SCHED);                     // the pushes are LDS round trips again
-        Q.push_each(have, to_walk ? (uint32_t)WQ_WALK : WQ_SHADE + cls, id, lane, failed);
+        Q.template push_all<HAS_MESH>(have, to_walk ? (uint32_t)WQ_WALK : WQ_SHADE + cls, id, lane, failed);
     };
     for (;;) {
         // Wave priority (s_setprio): the stage choice and the pop are a chain of dependent LDS round trips with a handful of instructions
@@ -313,6 +331,7 @@ DI void render_ctr_wavefront(const RenderParams& P) {
 #endif
         if (__ballot(failed) != 0ull) { if (lane == 0) atomicOr(&Q.ctrl[17], 1u); break; }
         if (__hip_atomic_load(&Q.ctrl[17], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { failed = true; break; }
+        // (all heads and tails with four 16-byte LDS reads instead of fourteen 4-byte ones: +-0 on all three scenes, round 5)
         const uint32_t cT1 = HAS_MESH ? Q.count(WQ_TOP1) : 0u, cW = HAS_MESH ? Q.count(WQ_WALK) : 0u;
         const uint32_t cS0 = Q.count(WQ_SHADE), cS1 = Q.count(WQ_SHADE + 1u), cS2 = Q.count(WQ_SHADE + 2u), cS3 = Q.count(WQ_SHADE + 3u);
         const uint32_t cF = wc.exhausted() ? 0u : Q.count(WQ_FREE);
