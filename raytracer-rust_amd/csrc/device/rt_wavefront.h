@@ -211,9 +211,6 @@ struct WfQueues {
 template <bool FIXED_AABB, uint32_t MATS, bool HAS_MESH = true, bool MESH_IDENT = false, int INLINE_STEPS = 8, int WF_ROUNDS = 3, int WF_STEPS = 8>
 DI void render_ctr_wavefront(const RenderParams& P) {
     typedef SlotIO Slot;
-#ifdef MI355RT_AB_WF_ASSUME
-    __builtin_assume(P.n_prims != 0u); __builtin_assume(P.max_depth != 0u);     // (the host sends the degenerate renders to the plain loop: rt_api.cpp render_samples)
-#endif
     constexpr uint32_t WF_PATHS = HAS_MESH ? mi355rt::WF_PATHS : WF_PATHS_MESHFREE, WF_SLOT_WORDS = HAS_MESH ? mi355rt::WF_SLOT_WORDS : 16u;
     constexpr uint32_t WF_LDS_WORDS = WF_CTRL_WORDS + WF_QUEUES * WF_RING / 2u + WF_PATHS * WF_SLOT_WORDS;
     static_assert(WF_LDS_WORDS <= WF_LDS_BUDGET_WORDS && WF_PATHS < WF_RING && WF_PATHS < WF_EMPTY, "wavefront kernel LDS budget / ring size");
