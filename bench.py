@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM
 VALU_SIMDS, VALU_CLOCK_HZ, VALU_CYCLES_PER_WAVE64_INST = 1024, 2.4e9, 2     # 256 CUs x 4 SIMDs; 157.3 TFLOP/s f32 = 1024 x 32 lanes x 2 x 2.4 GHz
 KERNEL_NAMES = {0: "k_render_ctr_nomesh", 1: "k_render_ctr_mesh", 2: "k_render_ctr_sm", 3: "k_render_ctr_simple", 4: "k_render_ctr_sm_fixaabb",
                 5: "(retired)", 6: "(retired)", 7: "k_render_ctr_wf", 8: "k_render_ctr_wf_fixaabb",
-                9: "k_render_ctr_nospec", 10: "k_render_ctr_wf_nometal", 11: "k_render_ctr_wf_meshfree", 12: "k_render_ctr_wf_nometal_ident", 13: "k_render_ctr_wf_nometal_shallow"}
+                9: "k_render_ctr_nospec", 10: "k_render_ctr_wf_nometal", 11: "k_render_ctr_wf_meshfree", 12: "k_render_ctr_wf_nometal_ident", 13: "k_render_ctr_wf_nometal_shallow", 14: "k_render_ctr_simple_qc"}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
 # What "roofline.pmc" says when the counters are used: they are NOT measured by this run.  SQ_INSTS_VALU per frame is a deterministic property of
 # (kernel binary, workload) -- the same paths, the same instructions -- so it is collected once per kernel hash by tools/pmc_collect.py (separate

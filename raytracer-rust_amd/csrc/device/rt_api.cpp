@@ -194,7 +194,7 @@ static int report_device_error(mi355rt_context* ctx, bool this_render) {
     ctx->err_reported = count;
     static const char* const kernel_names[KERNEL_VARIANTS] = {"k_render_ctr_nomesh", "k_render_ctr_mesh", "k_render_ctr_sm", "k_render_ctr_simple", "k_render_ctr_sm_fixaabb",
         "(retired)", "(retired)", "k_render_ctr_wf", "k_render_ctr_wf_fixaabb", "k_render_ctr_nospec", "k_render_ctr_wf_nometal", "k_render_ctr_wf_meshfree",
-        "k_render_ctr_wf_nometal_ident", "k_render_ctr_wf_nometal_shallow"};
+        "k_render_ctr_wf_nometal_ident", "k_render_ctr_wf_nometal_shallow", "k_render_ctr_simple_qc"};
     static const struct { uint32_t bit; const char* what; } waits[] = {
         {WAIT_WF_IDLE, "idle: no progress in the workgroup"}, {WAIT_WF_RING, "ring entry: a reserved ticket was never written, or an entry never emptied"},
         {WAIT_WF_FOLLOWED, "waves that followed their workgroup's error flag out"}};
@@ -493,8 +493,10 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
     for (const auto& pr : prims) n_mesh_prims += pr.kind == MI355RT_PRIM_MESH;
     const bool has_mesh = n_mesh_prims != 0;
     uint32_t scene_mats = 0u;                                        // which material kinds a ray can meet (bit k = MI355RT_MAT_k): those the primitives refer to
-    for (uint32_t i = 0; i < sc->n_primitives; ++i) scene_mats |= MATBIT(sc->materials[sc->primitives[i].material].kind);
+    uint32_t scene_prim_kinds = 0u;                                  // ... and which primitive kinds the list holds (bit k = MI355RT_PRIM_k)
+    for (uint32_t i = 0; i < sc->n_primitives; ++i) { scene_mats |= MATBIT(sc->materials[sc->primitives[i].material].kind); scene_prim_kinds |= 1u << sc->primitives[i].kind; }
     auto covers = [&](uint32_t variant) { return (scene_mats & ~mats_of_variant(variant)) == 0u; };
+    auto kinds_covered = [&](uint32_t variant) { return (scene_prim_kinds & ~prims_of_variant(variant)) == 0u; };          // likewise for the primitive kinds of the list
     ctx->has_mesh = has_mesh;
     // Scenes with meshes: the wavefront kernel (path state in LDS, stage queues).  No mesh: a lockstep kernel.  In both
     // families the most pruned instantiation whose material set covers the scene's (rt_device.h, mats_of_variant): the branches of
@@ -511,17 +513,17 @@ int build_device_scene(mi355rt_context* ctx, const mi355rt_scene* sc) {
         // passes run it at ~57 lanes: veach-mis 18.30 -> 16.75 ms at 256 spp.  Cheap mixtures (Lambert + metal + dielectric + plastic)
         // measured 3-7 % FASTER in lockstep (tools/ab_fuzz_scene.py), and so stay there.
         const bool rough = (scene_mats & MATS_ROUGH) != 0u, other_scatter = (scene_mats & ~(MATS_ROUGH | MATS_TERMINAL)) != 0u;
-        ctx->variant = covers(KERNEL_LOCKSTEP_SIMPLE) ? KERNEL_LOCKSTEP_SIMPLE
+        ctx->variant = covers(KERNEL_LOCKSTEP_SIMPLE) ? (kinds_covered(KERNEL_LOCKSTEP_SIMPLE_QC) ? KERNEL_LOCKSTEP_SIMPLE_QC : KERNEL_LOCKSTEP_SIMPLE)   // (... pruned to quads and cubes where the list holds nothing else: cornell)
                      : (rough && other_scatter && covers(KERNEL_WAVEFRONT_MESHFREE)) ? KERNEL_WAVEFRONT_MESHFREE
                      : covers(KERNEL_LOCKSTEP_NOSPEC) ? KERNEL_LOCKSTEP_NOSPEC : KERNEL_LOCKSTEP;
     }
     if (ctx->forced_variant >= 0) {
         const uint32_t v = (uint32_t)ctx->forced_variant;
-        const bool mesh_free_only = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_MESHFREE;
+        const bool mesh_free_only = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_SIMPLE_QC || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_MESHFREE;
         const bool selectable = v == KERNEL_LOCKSTEP || v == KERNEL_LOCKSTEP_MESH || v == KERNEL_STATE_MACHINE || v == KERNEL_WAVEFRONT ||
-                                v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_NOMETAL || v == KERNEL_WAVEFRONT_MESHFREE ||
+                                v == KERNEL_LOCKSTEP_SIMPLE || v == KERNEL_LOCKSTEP_SIMPLE_QC || v == KERNEL_LOCKSTEP_NOSPEC || v == KERNEL_WAVEFRONT_NOMETAL || v == KERNEL_WAVEFRONT_MESHFREE ||
                                 v == KERNEL_WAVEFRONT_NOMETAL_IDENT || v == KERNEL_WAVEFRONT_NOMETAL_SHALLOW;   // (the _FIXAABB forms follow options.flags; _SHALLOW is only a tuning: any tree is walked correctly)
-        const bool ok = render_ctr_variant_built(v) && selectable && covers(v) && !(mesh_free_only && has_mesh) &&
+        const bool ok = render_ctr_variant_built(v) && selectable && covers(v) && kinds_covered(v) && !(mesh_free_only && has_mesh) &&
                         !(v == KERNEL_WAVEFRONT_NOMETAL_IDENT && !(has_mesh && all_meshes_identity));     // (that form ASSUMES untransformed meshes)
         if (ok) ctx->variant = v;
     }
@@ -755,7 +757,7 @@ static int render_samples(mi355rt_context* ctx, const mi355rt_options* opt, uint
     }
     // The mesh-free lockstep kernels are compiled under the assumption that the list holds something and that a path may take a step (rt_kernels.hip,
     // render_ctr_lockstep); the two degenerate renders -- every sample is the miss colour / BLACK -- go to the plain per-lane loop, which assumes nothing.
-    if ((ctx->n_prims == 0 || st.max_depth == 0) && (variant == KERNEL_LOCKSTEP || variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_LOCKSTEP_NOSPEC))
+    if ((ctx->n_prims == 0 || st.max_depth == 0) && (variant == KERNEL_LOCKSTEP || variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_LOCKSTEP_SIMPLE_QC || variant == KERNEL_LOCKSTEP_NOSPEC))
         variant = KERNEL_LOCKSTEP_MESH;
     const uint64_t seed = opt ? opt->seed : 0;
     const uint32_t n_rows = (uint32_t)ctx->rows_host.size();

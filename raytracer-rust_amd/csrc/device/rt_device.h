@@ -129,8 +129,13 @@ enum : uint32_t {
     KERNEL_WAVEFRONT_MESHFREE = 11,  // the wavefront for lists WITHOUT a mesh, no metal / dielectric: material-sorted SHADE passes for scenes whose materials diverge (veach-mis)
     KERNEL_WAVEFRONT_NOMETAL_IDENT = 12,   // KERNEL_WAVEFRONT_NOMETAL for lists whose meshes are all untransformed (teapot): mesh_setup without its matrix products
     KERNEL_WAVEFRONT_NOMETAL_SHALLOW = 13, // KERNEL_WAVEFRONT_NOMETAL for lists whose meshes all have small trees (semesterbild): WALK passes of 3 x 6 instead of 3 x 8 box tests
-    KERNEL_VARIANTS = 14
+    KERNEL_LOCKSTEP_SIMPLE_QC = 14,  // KERNEL_LOCKSTEP_SIMPLE for lists of quads and cubes only (cornell): no sphere / plane run checks in the walk, a two-way finish_hit
+    KERNEL_VARIANTS = 15
 };
+// Primitive-kind sets (bit k = kind MI355RT_PRIM_k may occur), like the material sets below: the run checks and record branches of the other kinds are compiled out.
+constexpr uint32_t PRIMS_ALL = 0xFFFFFFFFu;
+constexpr uint32_t PRIMS_QUAD_CUBE = (1u << MI355RT_PRIM_QUAD) | (1u << MI355RT_PRIM_CUBE);
+inline uint32_t prims_of_variant(uint32_t variant) { return variant == KERNEL_LOCKSTEP_SIMPLE_QC ? PRIMS_QUAD_CUBE : PRIMS_ALL; }
 constexpr uint32_t WF_SHALLOW_NODES = 4096;      // "small tree": at most this many BVH nodes per mesh (a median-split tree of <= ~6 000 triangles, depth <= 11)
 // Material sets (bit k = kind MI355RT_MAT_k may occur) the kernels are instantiated for; set_scene picks, per kernel family, the
 // most pruned instantiation whose set covers the scene's materials.  The branches compiled out set the register peak.
@@ -143,7 +148,7 @@ constexpr uint32_t MATS_ROUGH = MATBIT(MI355RT_MAT_ROUGH_GGX) | MATBIT(MI355RT_M
 constexpr uint32_t MATS_NO_METAL = MATS_ALL & ~MATBIT(MI355RT_MAT_METAL);
 constexpr uint32_t MATS_NO_SPECULAR = MATS_ALL & ~(MATBIT(MI355RT_MAT_METAL) | MATBIT(MI355RT_MAT_DIELECTRIC));
 inline uint32_t mats_of_variant(uint32_t variant) {
-    return variant == KERNEL_LOCKSTEP_SIMPLE ? MATS_LAMBERT : (variant == KERNEL_LOCKSTEP_NOSPEC || variant == KERNEL_WAVEFRONT_MESHFREE) ? MATS_NO_SPECULAR
+    return (variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_LOCKSTEP_SIMPLE_QC) ? MATS_LAMBERT : (variant == KERNEL_LOCKSTEP_NOSPEC || variant == KERNEL_WAVEFRONT_MESHFREE) ? MATS_NO_SPECULAR
          : (variant == KERNEL_WAVEFRONT_NOMETAL || variant == KERNEL_WAVEFRONT_NOMETAL_IDENT || variant == KERNEL_WAVEFRONT_NOMETAL_SHALLOW) ? MATS_NO_METAL : MATS_ALL;
 }
 

@@ -350,8 +350,11 @@ DI bool hit_mesh(cprim_t pr, uint32_t i, const DevNode* __restrict__ nodes, cons
 
 // The HitRecord of the list's winner (hittable.rs:10-27), once per ray.  Lanes of a wave may have different winners, so
 // the primitive record is read per lane here (global loads; L1/L2 resident).
-template <bool HAS_MESH, bool SHARED_TAIL = !HAS_MESH, bool CARRY_Q0 = false, class C>
+// KINDS: bit k set = a primitive of kind k (MI355RT_PRIM_*) may occur in the list.  Like the material sets (MATS): set_scene knows which kinds a list holds and picks an
+// instantiation whose set covers them; the run checks of the other kinds in the walk and their branches here are compiled out (rt_device.h, PRIMS_*).
+template <bool HAS_MESH, bool SHARED_TAIL = !HAS_MESH, bool CARRY_Q0 = false, uint32_t KINDS = PRIMS_ALL, class C>
 DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__ tris, const C& c, f3 ro, f3 rd, Hit& h) {
+#define MI_KIND(k) (((KINDS >> (k)) & 1u) != 0u)
     const DevPrim* __restrict__ pr = prims + c.idx;
     const uint32_t kind = pr->kind;
     if constexpr (CARRY_Q0) h.q0 = *reinterpret_cast<const float4*>(pr->mat0);
@@ -361,13 +364,13 @@ DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__
     constexpr bool shared_tail = SHARED_TAIL;
     if (shared_tail) {
         f3 p = ro + rd * c.t, outward;                                        // sphere.rs:35, plane.rs:40, quad.rs:103
-        if (kind == MI355RT_PRIM_QUAD) {                                      // quad.rs:103-131
+        if (MI_KIND(MI355RT_PRIM_QUAD) && kind == MI355RT_PRIM_QUAD) {        // quad.rs:103-131
             outward = mk(pr->d[0], pr->d[1], pr->d[2]);                     // dot(ray.direction, normal): the same sum of the same products as `denom`
-        } else if (kind == MI355RT_PRIM_CUBE) {
+        } else if (MI_KIND(MI355RT_PRIM_CUBE) && (kind == MI355RT_PRIM_CUBE || KINDS == PRIMS_QUAD_CUBE)) {      // (two kinds: what is not a quad is a cube)
             finish_cube(pr, c, ro, rd, p, outward);
-        } else if (kind == MI355RT_PRIM_SPHERE) {                             // sphere.rs:35-52
+        } else if (MI_KIND(MI355RT_PRIM_SPHERE) && kind == MI355RT_PRIM_SPHERE) {   // sphere.rs:35-52
             outward = divf(p - mk(pr->d[0], pr->d[1], pr->d[2]), pr->d[3]);
-        } else if (kind == MI355RT_PRIM_PLANE) {                              // plane.rs:40-55
+        } else if (MI_KIND(MI355RT_PRIM_PLANE) && kind == MI355RT_PRIM_PLANE) {     // plane.rs:40-55
             outward = mk(pr->d[3], pr->d[4], pr->d[5]);
         } else if (HAS_MESH) {
             finish_mesh(pr, reinterpret_cast<const float4*>(tris), c, ro, rd, p, outward);
@@ -395,11 +398,13 @@ DI void finish_hit(const DevPrim* __restrict__ prims, const DevTri* __restrict__
     }
 }
 
+#undef MI_KIND
 DI uint32_t prim_material_kind(const RenderParams& P, uint32_t idx) { return __float_as_uint(P.prims[idx].mat0[0]); }   // one read, not two dependent ones
 
 // hittable.rs:45-58 -- HittableList::hit with t_min = EPSILON, t_max = INFINITY (renderer.rs:24)
-template <bool HAS_MESH, class C>
+template <bool HAS_MESH, uint32_t KINDS = PRIMS_ALL, class C>
 DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris, f3 ro, f3 rd, C& c) {
+#define MI_KIND(k) (((KINDS >> (k)) & 1u) != 0u)
     // Same order as the list, but the dispatch on the kind (wave-uniform: a scalar branch) is taken once per RUN of equal kinds
     // (DevPrim.run_end, host-computed) and each kind has its own tight loop: the structurised switch inside one loop carried the
     // candidate through a chain of merge blocks with register copies at every one of them.
@@ -410,25 +415,27 @@ DI void walk_list(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ n
     uint32_t i = 0;
     while (i < n_prims) {
 #define MI_RUN(KIND, CALL) if (i < n_prims && prims[i].kind == (KIND)) { const uint32_t end = min(prims[i].run_end, n_prims); do { CALL; } while (++i < end); }
-        MI_RUN(MI355RT_PRIM_QUAD,   hit_quad<!HAS_MESH>(prims + i, i, ro, rd, EPS, c))
-        MI_RUN(MI355RT_PRIM_CUBE,   hit_cube<!HAS_MESH>(prims + i, i, ro, rd, EPS, c))
-        MI_RUN(MI355RT_PRIM_SPHERE, hit_sphere(prims + i, i, ro, rd, EPS, c))
-        MI_RUN(MI355RT_PRIM_PLANE,  hit_plane(prims + i, i, ro, rd, EPS, c))
+        if (MI_KIND(MI355RT_PRIM_QUAD)) { MI_RUN(MI355RT_PRIM_QUAD,   hit_quad<!HAS_MESH>(prims + i, i, ro, rd, EPS, c)) }
+        if (MI_KIND(MI355RT_PRIM_CUBE)) { MI_RUN(MI355RT_PRIM_CUBE,   hit_cube<!HAS_MESH>(prims + i, i, ro, rd, EPS, c)) }
+        if (MI_KIND(MI355RT_PRIM_SPHERE)) { MI_RUN(MI355RT_PRIM_SPHERE, hit_sphere(prims + i, i, ro, rd, EPS, c)) }
+        if (MI_KIND(MI355RT_PRIM_PLANE)) { MI_RUN(MI355RT_PRIM_PLANE,  hit_plane(prims + i, i, ro, rd, EPS, c)) }
         if (HAS_MESH) { MI_RUN(MI355RT_PRIM_MESH, hit_mesh(prims + i, i, nodes, tris, ro, rd, EPS, c)) }
-        else if (i < n_prims && prims[i].kind >= MI355RT_PRIM_MESH) ++i;          // cannot happen (the host picks this kernel only for mesh-free lists); keeps the loop finite
+        else if (KINDS == PRIMS_ALL) { if (i < n_prims && prims[i].kind >= MI355RT_PRIM_MESH) ++i; }   // cannot happen (the host picks this kernel only for mesh-free lists); keeps the loop finite
+        else if (i < n_prims && ((KINDS >> prims[i].kind) & 1u) == 0u) ++i;                               // likewise for a pruned set of kinds
 #undef MI_RUN
+#undef MI_KIND
     }
 }
 // CARRY_PO: the candidate keeps the cube's object-space hit point (CandP).  On for both mesh-free kernels: the Lambert-only one
 // (cornell -1.8 % at 72 VGPRs) and the general one, which needs 80 VGPRs = 6 waves per SIMD for it (veach-mis: +1.9 % at 72 with
 // spills, -2.6 % at 80; see MI355RT_OCC_LOCKSTEP).
-template <bool HAS_MESH, bool CARRY_PO = false>
+template <bool HAS_MESH, bool CARRY_PO = false, uint32_t KINDS = PRIMS_ALL>
 DI bool hit_scene(cprim_t prims, uint32_t n_prims, const DevNode* __restrict__ nodes, const DevTri* __restrict__ tris,
                   f3 ro, f3 rd, Hit& best) {
     typename std::conditional<CARRY_PO && !HAS_MESH, CandP, Cand>::type c; cand_reset(c);
-    walk_list<HAS_MESH>(prims, n_prims, nodes, tris, ro, rd, c);
+    walk_list<HAS_MESH, KINDS>(prims, n_prims, nodes, tris, ro, rd, c);
     if (c.idx == CAND_NONE) return false;
-    finish_hit<HAS_MESH, !HAS_MESH, !HAS_MESH>((const DevPrim*)prims, tris, c, ro, rd, best);          // (the lockstep kernels' entry: q0 rides along when there is no mesh)
+    finish_hit<HAS_MESH, !HAS_MESH, !HAS_MESH, KINDS>((const DevPrim*)prims, tris, c, ro, rd, best);          // (the lockstep kernels' entry: q0 rides along when there is no mesh)
     return true;
 }
 

@@ -409,7 +409,7 @@ DI bool shade_and_regenerate(const RenderParams& P, WC& wc, uint32_t lane, bool&
 // The lockstep kernels' forms (each measured against its alternative; docs/kernels/lockstep_round3.md): the candidate carries the cube's object-space hit
 // point (also in the general kernel: pays at 80 VGPRs); the short reciprocal / square root / division of rt_math.h; in the Lambert-only kernel ONE try of the
 // unit-ball draw in the lane itself before the cooperative rounds (0 tries: +1.9 %, 2 tries: +-0 with pcg4d, +23 % with Philox: profiles/r05/ab_counter_generator.txt).
-template <bool HAS_MESH, uint32_t MATS>
+template <bool HAS_MESH, uint32_t MATS, uint32_t KINDS = PRIMS_ALL>
 DI void render_ctr_lockstep(const RenderParams& P) {
     constexpr bool SIMPLE = (MATS & ~MATS_LAMBERT) == 0u;
     // The mesh-free kernels are compiled for lists that hold something and for paths that may take a step: the host sends an empty list or max_depth == 0 to
@@ -440,7 +440,7 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         // wave whose loads can then be in flight under the others' arithmetic.  cornell 16.49 -> 15.82 ms, veach-mis on these kernels -1.7 %;
         // priority 2 or 3 measure the same; keeping it through Philox (15.96) or only over the walk (16.10-16.17) gains less.
         __builtin_amdgcn_s_setprio(1);
-        if (live) hit = hit_scene<HAS_MESH, true>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
+        if (live) hit = hit_scene<HAS_MESH, true, KINDS>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);
         if (!shade_and_regenerate<MATS, false, true, true, !HAS_MESH, /* FASTN */ true, /* TRY1 */ SIMPLE ? 1 : 0>(P, wc, lane, live, true, hit, h, ps, n_paths, n_rays, prof, stock)) break;
         prof.mark(4);
@@ -474,6 +474,8 @@ DI void render_ctr_lockstep(const RenderParams& P) {
 //   k_render_ctr_mesh    lockstep with the per-lane BVH walk inlined   (A/B reference for the state machine)
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_nomesh(const RenderParams P) { render_ctr_lockstep<false, MATS_ALL>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_simple(const RenderParams P) { render_ctr_lockstep<false, MATS_LAMBERT>(P); }
+// ... and the Lambert-only kernel for lists of quads and cubes (round 5: cornell -1.1 %, profiles/r05/ab_scalar_diet.txt r05_q16)
+__global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_simple_qc(const RenderParams P) { render_ctr_lockstep<false, MATS_LAMBERT, PRIMS_QUAD_CUBE>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_nospec(const RenderParams P) { render_ctr_lockstep<false, MATS_NO_SPECULAR>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_render_ctr_mesh(const RenderParams P) { render_ctr_lockstep<true, MATS_ALL>(P); }
 
@@ -638,6 +640,7 @@ int launch_render_ctr(const RenderParams& p, uint32_t variant, uint32_t grid_blo
         case KERNEL_LOCKSTEP:        hipLaunchKernelGGL(k_render_ctr_nomesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_MESH:   hipLaunchKernelGGL(k_render_ctr_mesh, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_SIMPLE: hipLaunchKernelGGL(k_render_ctr_simple, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
+        case KERNEL_LOCKSTEP_SIMPLE_QC: hipLaunchKernelGGL(k_render_ctr_simple_qc, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_LOCKSTEP_NOSPEC: hipLaunchKernelGGL(k_render_ctr_nospec, dim3(grid_blocks), dim3(BLOCK_THREADS), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_MESHFREE: hipLaunchKernelGGL(k_render_ctr_wf_meshfree, dim3(grid_blocks), dim3(BLOCK_THREADS_WF_MESHFREE), 0, (hipStream_t)stream, p); break;
         case KERNEL_WAVEFRONT_NOMETAL: hipLaunchKernelGGL(k_render_ctr_wf_nometal, dim3(grid_blocks), dim3(BLOCK_THREADS_WF), 0, (hipStream_t)stream, p); break;
@@ -657,7 +660,7 @@ bool render_ctr_variant_built(uint32_t variant) {
 #ifdef MI355RT_REFS
     return variant < KERNEL_VARIANTS && variant != KERNEL_RETIRED_5 && variant != KERNEL_RETIRED_6;
 #else
-    return variant == KERNEL_LOCKSTEP || variant == KERNEL_LOCKSTEP_MESH || variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_LOCKSTEP_NOSPEC ||
+    return variant == KERNEL_LOCKSTEP || variant == KERNEL_LOCKSTEP_MESH || variant == KERNEL_LOCKSTEP_SIMPLE || variant == KERNEL_LOCKSTEP_SIMPLE_QC || variant == KERNEL_LOCKSTEP_NOSPEC ||
            is_wavefront(variant);
 #endif
 }
@@ -675,6 +678,7 @@ int query_render_ctr_occupancy(uint32_t variant, int* blocks_per_cu, int* vgprs,
     const void* fn = variant == KERNEL_LOCKSTEP ? reinterpret_cast<const void*>(k_render_ctr_nomesh)
                    : variant == KERNEL_LOCKSTEP_MESH ? reinterpret_cast<const void*>(k_render_ctr_mesh)
                    : variant == KERNEL_LOCKSTEP_SIMPLE ? reinterpret_cast<const void*>(k_render_ctr_simple)
+                   : variant == KERNEL_LOCKSTEP_SIMPLE_QC ? reinterpret_cast<const void*>(k_render_ctr_simple_qc)
                    : variant == KERNEL_LOCKSTEP_NOSPEC ? reinterpret_cast<const void*>(k_render_ctr_nospec)
                    : variant == KERNEL_WAVEFRONT_NOMETAL ? reinterpret_cast<const void*>(k_render_ctr_wf_nometal)
                    : variant == KERNEL_WAVEFRONT_NOMETAL_IDENT ? reinterpret_cast<const void*>(k_render_ctr_wf_nometal_ident)

@@ -82,5 +82,5 @@ def test_product_libraries_read_no_environment_and_hold_no_retired_kernels(nativ
         assert "getenv" not in undef, so
     syms = subprocess.run(["nm", b.DEVICE_SO], capture_output=True, text=True, check=True).stdout
     kernels = set(re.findall(r"k_render_ctr_[a-z_]+", syms))
-    assert kernels == {"k_render_ctr_nomesh", "k_render_ctr_simple", "k_render_ctr_nospec", "k_render_ctr_mesh",
+    assert kernels == {"k_render_ctr_nomesh", "k_render_ctr_simple", "k_render_ctr_simple_qc", "k_render_ctr_nospec", "k_render_ctr_mesh",
                        "k_render_ctr_wf", "k_render_ctr_wf_nometal", "k_render_ctr_wf_nometal_ident", "k_render_ctr_wf_nometal_shallow", "k_render_ctr_wf_meshfree", "k_render_ctr_wf_fixaabb"}, kernels

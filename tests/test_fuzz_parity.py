@@ -77,7 +77,8 @@ def test_state_machine_corner_shapes(label, kw, native, oracle_mod, abi):
     ("alternating kinds (runs of one)", dict(n_prims=12, only_kinds=[3, 2, 0, 1]), 0),
     ("one long run", dict(n_prims=40, only_kinds=[2]), 0),
     ("Lambert-only list", dict(n_prims=14, only_kinds=[2, 2, 2, 3, 3, 2, 0, 1, 3], lambert_only=True), 3),
-    ("Lambert-only cubes", dict(n_prims=9, only_kinds=[3], lambert_only=True), 3),
+    ("Lambert-only cubes", dict(n_prims=9, only_kinds=[3], lambert_only=True), 14),                         # quads and cubes only: the instantiation pruned to those two kinds
+    ("Lambert-only quads and cubes", dict(n_prims=13, only_kinds=[2, 3, 3, 2, 2], lambert_only=True), 14),
 ])
 @pytest.mark.parametrize("seed", [31, 32, 33])
 def test_lockstep_kernels_on_mesh_free_fuzz_scenes(label, kw, kernel, seed, native, oracle_mod, abi):

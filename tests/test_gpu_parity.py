@@ -174,8 +174,11 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, knobs):
     v, gp, gl, rays = run(sc)
     knobs(kernel=0)
     v0, gp0, gl0, rays0 = run(sc)
-    assert (v, v0) == (3, 0), "the simple-materials instantiation was not selected for cornell"
+    knobs(kernel=3)                                       # the Lambert-only kernel for any primitive kinds
+    v3, gp3, gl3, rays3 = run(sc)
+    assert (v, v0, v3) == (14, 0, 3), "the simple-materials instantiation (pruned to quads and cubes: cornell holds nothing else) was not selected for cornell"
     assert np.array_equal(gl.view(np.uint32), gl0.view(np.uint32)) and np.array_equal(gp, gp0) and rays == rays0
+    assert np.array_equal(gl.view(np.uint32), gl3.view(np.uint32)) and np.array_equal(gp, gp3) and rays == rays3
     op, ol, cnt = oracle_mod.render(sc, sc.camera, sc.settings, abi.Options.make())
     assert np.array_equal(gl.view(np.uint32), ol.reshape(-1).view(np.uint32)) and cnt.rays == rays
 
@@ -206,6 +209,13 @@ def test_simple_material_kernel_equals_general(native, oracle_mod, abi, knobs):
     assert run(sm)[0] == 0
     knobs(kernel=11)
     assert run(sm)[0] == 0
+    # ... the instantiation pruned to quads and cubes is refused for a list that holds a sphere (and is not picked for it)
+    ss = random_scene(abi, host, 33, exact_only=True, n_prims=9, only_kinds=[2, 3, 0], lambert_only=True)
+    ss.settings = abi.Settings(40, 30, 3, 6)
+    knobs()
+    assert run(ss)[0] == 3
+    knobs(kernel=14)
+    assert run(ss)[0] == 3
     # ... and a mesh-free wavefront kernel is refused for a list with a mesh
     st = load_for_both("teapot", oracle_mod, host, width=48, height=32, spp=2, max_depth=4)
     knobs(kernel=11)

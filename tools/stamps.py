@@ -25,7 +25,7 @@ for name, path, W, H, spp, depth, skip in [("cornell", "data/scenes/tungsten/cor
     for n, v in zip(NAMES, acc):
         if v: print(f"   {n:38s} {100 * v / acc.sum():6.2f} %")
     cl = list(raw)[24:34]
-    if sum(cl) and ctx.kernel_variant() in (0, 3, 9):
+    if sum(cl) and ctx.kernel_variant() in (0, 3, 9, 14):
         iters = cl[8]                   # wave iterations with at least one lane to shade
         print(f"   shading step: {iters / (st.rays / 64.0):.2f} wave iterations per 64 rays, {cl[9] / max(iters, 1):.1f} lanes with a ray to produce")
         for i, n in enumerate(["rough conductor branch", "Lambert-style bounce (cooperative unit ball)", "metal / dielectric branch", "camera ray (fresh path)"]):
