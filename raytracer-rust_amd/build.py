@@ -48,14 +48,35 @@ def _host_deps():
     return _host_srcs() + hs + [os.path.join(ROOT, "include", "mi355rt.h")]
 
 
+def _code_only(text):
+    """C++ source without its comments, whitespace runs collapsed (string and character literals are kept as they are)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":                                      # a literal: copy to its closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i); i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2); i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_hash():
     """sha256 over everything that decides the device code AND how it is launched: the kernel source, every header of csrc/device, the
-    host half (rt_api.cpp: grid size, shard size, guided_div, the choice of the kernel variant) and the hipcc flags.
+    host half (rt_api.cpp: grid size, shard size, guided_div, the choice of the kernel variant) and the hipcc flags -- the CODE of those
+    files: comments and whitespace are stripped first, so that correcting a comment does not orphan the committed counters.
     profiles/pmc_counters.json records it, and bench.py refuses counters taken on another library."""
     import hashlib
     h = hashlib.sha256()
     for f in DEVICE_SRCS + DEVICE_HEADERS:                  # rt_kernels.hip, rt_api.cpp and every header they include (rt_device.h, rt_math.h, ...)
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, encoding="utf-8").read()).encode())
     h.update(" ".join(HIPCC_FLAGS).encode())
     return h.hexdigest()[:16]
 

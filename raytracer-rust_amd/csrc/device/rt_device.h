@@ -3,7 +3,7 @@
 // HBM layout (all arrays 16-byte aligned, record sizes multiples of 16 bytes so that the
 // wave-uniform top-level walk lowers to s_load_dwordx4/x8/x16 and the per-lane BVH walk to
 // global_load_dwordx4):
-//   DevPrim[n_prims]   224 B  top-level list in caller order (hittable.rs:45-58), read through the
+//   DevPrim[n_prims]   240 B  top-level list in caller order (hittable.rs:45-58), read through the
 //                             constant address space with a wave-uniform index -> SGPRs
 //   DevMat[n_mats]      64 B  per-lane gather by material index (4 x dwordx4)
 //   DevNode[n_nodes]    32 B  two-link BVH nodes, stored level by level (all meshes' roots, then their children, ...):

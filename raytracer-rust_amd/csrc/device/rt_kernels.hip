@@ -12,16 +12,18 @@
 //                  pre-order array walked per lane with dwordx4 loads -- the reference always descends
 //                  left-then-right (bvh.rs:142-156), so escape links reproduce its visit order and its
 //                  shrinking t_max exactly and no traversal stack is needed.
-//                  Randomness: counter-based Philox4x32-10 keyed by the image row, counters
-//                  (x, sample, ray index, block): every draw is a pure function of the path, so any
-//                  schedule / tiling / GPU count produces bit-identical radiance.
+//                  Randomness: a counter-based generator (pcg4d since round 5; Philox4x32-10 / -7 selectable at build time,
+//                  rt_rng.h) addressed by (image row key; x, sample, ray index, block): every draw is a pure function of
+//                  the path, so any schedule / tiling / GPU count produces bit-identical radiance.
+//                  Round 5: a wave keeps the camera rays of its next 64 samples IN STOCK (RayStock, LDS) and the mesh-free kernels
+//                  are instantiated per material set AND per primitive-kind set (k_render_ctr_simple_qc).
 //                  Output: three floats of radiance per path into the HBM workspace.
 //   k_resolve      per pixel, sums its spp radiance values IN SAMPLE ORDER (renderer.rs:100), scales by
 //                  1/spp (:103), sqrt-gamma, clamp, pack 0x00RRGGBB (:112-120, color.rs:87-93).
 //   k_render_ref   validation mode: one lane per image row replays the reference's sequential
 //                  StdRng::seed_from_u64(y) stream (renderer.rs:91) and folds radiance tail-first.
 //
-// Files (one translation unit; this file includes the rest): rt_math.h (vec3.rs helpers), rt_rng.h (Philox / ChaCha12 replay),
+// Files (one translation unit; this file includes the rest): rt_math.h (vec3.rs helpers), rt_rng.h (pcg4d / Philox, ChaCha12 replay),
 // rt_intersect.h (hit tests, BVH walk, finish_hit), rt_materials.h (scatter, camera, miss colour), here: the work cursor,
 // shade_and_regenerate() and the lockstep kernels, then rt_mesh_variants.h (the state machine of the reference build), rt_wavefront.h
 // (k_render_ctr_wf), and at the end k_resolve, k_render_ref, the debug kernels and the launchers.
@@ -257,16 +259,16 @@ DI f3 unit_ball_cooperative(bool diffuse, const RngCtr& rng, uint32_t lane, cons
 // The shading half of one trace_ray level (renderer.rs:26-36) plus path regeneration, for every lane of the
 // wave at once.  On entry `live` lanes carry a finished intersection (`hit`, `h`); on exit `live` lanes carry
 // the next ray to trace.  Order: finish paths that end without scattering (miss / emitter / null) ->
-// deal fresh samples to idle lanes -> ONE Philox call for all lanes -> camera ray (fresh) or BSDF (continuing).
+// deal fresh samples to idle lanes -> ONE generator call for all lanes -> camera ray (fresh) or BSDF (continuing).
 // Must be called by the whole wave in uniform control flow (it ballots): lanes that are busy elsewhere
 // pass live = false and can_take = false and are left untouched.
 // Returns false when no lane is live afterwards and no work is left to deal.
 // DEFAULTS: give the per-lane temporaries default values.  The lockstep kernels run without (every value is read only on the
 // path that wrote it, and the defaults cost ~30 v_mov per iteration: cornell -1.5 %), and since round 3 so does the wavefront
 // kernel (rt_wavefront.h); the reference build's state machine keeps them (its other lanes'
-// state must not be touched).  WIDE: Philox on 64-bit products (rt_rng.h).  DROP_PRIO: lower the wave's priority to 0 once the
+// state must not be touched).  WIDE: the generator's multiplies as 64-bit products (rt_rng.h).  DROP_PRIO: lower the wave's priority to 0 once the
 // fresh samples are dealt (the caller raised it for the memory-bound half of the iteration).  Q0_IN_HIT: see struct Hit.
-// FASTN: see normalized() (rt_math.h).  TRY1: try 1 of the unit-ball draw comes from a second Philox block drawn in the lane itself, right after the
+// FASTN: see normalized() (rt_math.h).  TRY1: try 1 of the unit-ball draw comes from a second generator block drawn in the lane itself, right after the
 // event's block, so the cooperative rounds start at try 2 and a second round is needed in 44 % of the iterations instead of all: cornell -0.9 %
 // on the Lambert-only kernel; every other kernel pays for the three more live registers with spills (+1.5 ... +23 %: profiles/r03_ab_inlane_try1.txt).
 // REKEY (wavefront kernel: a path's generator state is not carried in its slot): the state is derived from the sample index HERE, once, for continuing
@@ -436,9 +438,11 @@ DI void render_ctr_lockstep(const RenderParams& P) {
         Hit h; bool hit = false;                           // h is read only where `hit` says it was written: no default values to copy around
         // Wave priority by phase (round 3; profiles/r03_ab_lockstep_priority.txt): the half of an iteration that waits on memory -- the
         // list walk's primitive reads, the material read, the radiance store and the work cursor's atomic -- runs at priority 1, the
-        // arithmetic half (Philox, BSDF, the cooperative unit-ball draw, the next ray) at 0, so a SIMD's issue slots go first to the
+        // arithmetic half (generator, BSDF, the cooperative unit-ball draw, the next ray) at 0, so a SIMD's issue slots go first to the
         // wave whose loads can then be in flight under the others' arithmetic.  cornell 16.49 -> 15.82 ms, veach-mis on these kernels -1.7 %;
-        // priority 2 or 3 measure the same; keeping it through Philox (15.96) or only over the walk (16.10-16.17) gains less.
+        // priority 2 or 3 measure the same; keeping it through the generator call (15.96) or only over the walk (16.10-16.17) gains less.
+        // (Round 5, after the scalar diet: all four schemes -- 1/0, none, inverted, 3/0 -- are within 0.2 % of each other; the list walk no longer waits.
+        //  profiles/r05/ab_scalar_diet.txt r05_q13.)
         __builtin_amdgcn_s_setprio(1);
         if (live) hit = hit_scene<HAS_MESH, true, KINDS>(prims, P.n_prims, P.nodes, P.tris, ps.ro, ps.rd, h);     // renderer.rs:24
         prof.mark(1);

@@ -1,4 +1,4 @@
-// rt_rng.h -- the two samplers: counter-mode Philox4x32-10 (RngCtr) and the replay of rand_chacha ChaCha12 (RngRef)
+// rt_rng.h -- the two samplers: the counter-mode generator (RngCtr: pcg4d since round 5, Philox4x32-10 / -7 at build time) and the replay of rand_chacha ChaCha12 (RngRef)
 // Part of the device code of libmi355rt.so; included by rt_kernels.hip only (one translation unit: every kernel sees the same
 // inlined device functions, and build.kernel_hash() covers every file of this directory).
 #pragma once

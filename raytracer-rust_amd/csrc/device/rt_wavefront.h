@@ -3,7 +3,7 @@
 // inlined device functions, and build.kernel_hash() covers every file of this directory).
 #pragma once
 
-// shade_and_regenerate's form in the wavefront kernel (rt_kernels.hip): without default values and with Philox on 64-bit products,
+// shade_and_regenerate's form in the wavefront kernel (rt_kernels.hip): without default values and with the generator's multiplies as 64-bit products,
 // like the lockstep kernels.  Round 2 measured both the other way round (38 spilled registers with defaults, 120 without; the wide
 // multiply 2-3 % slower) -- on a kernel whose SHADE spilled 50 registers.  With the metal's loop gone and the material sets
 //  the allocation has room: semesterbild / teapot 800x600x256 (ms): defaults + narrow 28.45 / 16.88, defaults + wide

@@ -68,3 +68,21 @@ def test_frames_in_flight_fall_back_to_the_queue_classes_that_exist():
     assert bench.fit_frames_to_queues(4, 4, unprobed) == (4, 4, unprobed)                      # nothing known: as chosen
     assert bench.fit_frames_to_queues(4, 4, {"queue_classes_found": 2}, auto=False)[:2] == (4, 4)   # typed by the user: as typed
     assert bench.fit_frames_to_queues(1, 1, None) == (1, 1, None)
+
+
+def test_kernel_hash_covers_the_code_not_the_comments(tmp_path, monkeypatch):
+    """profiles/pmc_counters.json is tied to the kernel sources by build.kernel_hash(); the hash is over their CODE (comments and whitespace stripped), so
+    that correcting a comment does not orphan the committed counters -- while any change of a token, in a kernel, a header or the host half, does."""
+    build = pkg("build")
+    assert build._code_only('int a = 1; // c1\n/* c2 */ const char* s = "x // kept"; char q = \'"\'; // "z\n  int   b;') == 'int a = 1; const char* s = "x // kept"; char q = \'"\'; int b;'
+    src = tmp_path / "k.hip"; hdr = tmp_path / "h.h"
+    src.write_text("__global__ void k(int* p) { *p = 1; }  // one\n"); hdr.write_text("#define X 1\n")
+    monkeypatch.setattr(build, "DEVICE_SRCS", [str(src)]); monkeypatch.setattr(build, "DEVICE_HEADERS", [str(hdr)])
+    h0 = build.kernel_hash()
+    src.write_text("__global__ void k(int* p)   {\n  *p = 1;   /* another comment */ }\n")
+    assert build.kernel_hash() == h0
+    src.write_text("__global__ void k(int* p) { *p = 2; }\n")
+    assert build.kernel_hash() != h0
+    hdr.write_text("#define X 2\n"); h1 = build.kernel_hash()
+    monkeypatch.setattr(build, "HIPCC_FLAGS", build.HIPCC_FLAGS + ["-O2"])
+    assert build.kernel_hash() != h1
