@@ -472,10 +472,11 @@ DI void render_ctr_lockstep(const RenderParams& P) {
 }
 
 // Entry points: one body, instantiated per scene class so that each gets its own register budget.
-//   k_render_ctr_nomesh  any materials, no mesh in the list            (veach-mis)                7 waves/SIMD
-//   k_render_ctr_simple  Lambertian/Emissive/Null only, no mesh        (cornell: -3 % vs nomesh)   7 waves/SIMD
-//   k_render_ctr_nospec  no metal, no dielectric, no mesh              (veach-mis: -2.5 % vs nomesh) 7 waves/SIMD
-//   k_render_ctr_mesh    lockstep with the per-lane BVH walk inlined   (A/B reference for the state machine)
+//   k_render_ctr_nomesh     any materials, no mesh in the list                      (any other mesh-free list)                        6 waves/SIMD
+//   k_render_ctr_simple     Lambertian/Emissive/Null only, no mesh                  (-3 % vs nomesh on cornell)                       7 waves/SIMD
+//   k_render_ctr_simple_qc  the same for lists of quads and cubes only              (cornell: another -1.1 %)                         7 waves/SIMD
+//   k_render_ctr_nospec     no metal, no dielectric, no mesh                        (-2.5 % vs nomesh on veach-mis; the probe kernel) 7 waves/SIMD
+//   k_render_ctr_mesh       lockstep with the per-lane BVH walk inlined             (diagnostic knob; the two degenerate renders: an empty list, max_depth 0)
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_LS k_render_ctr_nomesh(const RenderParams P) { render_ctr_lockstep<false, MATS_ALL>(P); }
 __global__ void __launch_bounds__(BLOCK_THREADS) MI355RT_OCC_SIMPLE k_render_ctr_simple(const RenderParams P) { render_ctr_lockstep<false, MATS_LAMBERT>(P); }
 // ... and the Lambert-only kernel for lists of quads and cubes (round 5: cornell -1.1 %, profiles/r05/ab_scalar_diet.txt r05_q16)
