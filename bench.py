@@ -148,8 +148,9 @@ def main(argv=None):
                          "a healthy 8-rank launch needs well under a minute once the image is paged in")
     ap.add_argument("--teardown-grace", type=float, default=20.0,
                     help="`--gpus N` as typed: seconds a launch may take to exit after its result line before it is ended (its line stands, exit code 0)")
-    ap.add_argument("--rendezvous-timeout", type=float, default=60.0,
-                    help="rank path: timeout of init_process_group and of every collective (torch's default for nccl is 10 minutes)")
+    ap.add_argument("--rendezvous-timeout", type=float, default=120.0,
+                    help="rank path: timeout of init_process_group and of every collective (torch's default for nccl is 10 minutes, longer than a driver's whole "
+                         "limit; 120 s leaves room for ranks whose first `import torch` on a fresh box pages the image in at different speeds)")
     ap.add_argument("--no-one-shot", action="store_true", help="skip the one-shot mi355rt_render timing (N = 1) that the line carries as `one_shot`")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without a launcher: one process, one context + stream per device, gather by device-to-device copies into device 0 "
